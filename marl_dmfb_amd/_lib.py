@@ -1,0 +1,79 @@
+"""ctypes loader for the HIP libraries built in-tree (marl_dmfb_amd/lib/*.so).
+
+Fails loudly when a library is missing: the product path has no CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, 'lib')
+_CACHE = {}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load(name):
+    if name in _CACHE:
+        return _CACHE[name]
+    path = os.path.join(LIB_DIR, 'lib%s.so' % name)
+    if not os.path.exists(path):
+        raise HipLibraryMissing(
+            '%s not found: build the HIP extension first (python -c "import __graft_entry__ as g; g.build()" '
+            'or make -C marl_dmfb_amd/csrc). There is no CPU fallback.' % path)
+    lib = C.CDLL(path)
+    _CACHE[name] = lib
+    return lib
+
+
+class DmfbVecConfig(C.Structure):
+    """include/dmfb_vec.h: dmfb_vec_config"""
+    _fields_ = [('width', C.c_int32), ('length', C.c_int32), ('n_agents', C.c_int32), ('n_blocks', C.c_int32),
+                ('fov', C.c_int32), ('stall', C.c_int32), ('b_degrade', C.c_int32), ('with_maps', C.c_int32),
+                ('per_degrade', C.c_double), ('n_envs', C.c_int32), ('env_id0', C.c_uint32), ('seed', C.c_uint64),
+                ('device', C.c_int32)]
+
+
+class DmfbVecStepOut(C.Structure):
+    """include/dmfb_vec.h: dmfb_vec_step_out"""
+    _fields_ = [('d_rewards', C.c_void_p), ('d_dones', C.c_void_p), ('d_constraints', C.c_void_p),
+                ('d_success', C.c_void_p), ('d_obs', C.c_void_p), ('d_team_reward', C.c_void_p),
+                ('d_terminated', C.c_void_p)]
+
+
+DMFB_VEC_SYMBOLS = [
+    'dmfb_vec_check_config', 'dmfb_vec_create', 'dmfb_vec_destroy', 'dmfb_vec_state_bytes', 'dmfb_vec_obs_len',
+    'dmfb_vec_max_step', 'dmfb_vec_n_envs', 'dmfb_vec_n_agents', 'dmfb_vec_reset', 'dmfb_vec_restart',
+    'dmfb_vec_set_task', 'dmfb_vec_get_task', 'dmfb_vec_step', 'dmfb_vec_observe', 'dmfb_vec_get_state',
+    'dmfb_vec_get_map', 'dmfb_vec_set_map', 'dmfb_vec_zoom_lut', 'dmfb_vec_strerror', 'dmfb_vec_last_hip_error',
+]
+
+
+def dmfb_vec():
+    lib = load('dmfb_vec')
+    if getattr(lib, '_typed', False):
+        return lib
+    vp, i32, u32 = C.c_void_p, C.c_int, C.c_uint32
+    cfgp = C.POINTER(DmfbVecConfig)
+    lib.dmfb_vec_check_config.argtypes = [cfgp]
+    lib.dmfb_vec_create.argtypes = [cfgp, vp, C.POINTER(vp)]
+    lib.dmfb_vec_destroy.argtypes = [vp]
+    lib.dmfb_vec_state_bytes.argtypes = [vp]
+    lib.dmfb_vec_state_bytes.restype = C.c_size_t
+    for f in ('dmfb_vec_obs_len', 'dmfb_vec_max_step', 'dmfb_vec_n_envs', 'dmfb_vec_n_agents'):
+        getattr(lib, f).argtypes = [vp]
+    lib.dmfb_vec_reset.argtypes = [vp, vp, i32, vp, vp]
+    lib.dmfb_vec_restart.argtypes = [vp, vp, vp, vp]
+    lib.dmfb_vec_set_task.argtypes = [vp, vp, vp, vp]
+    lib.dmfb_vec_get_task.argtypes = [vp, vp, vp, vp]
+    lib.dmfb_vec_step.argtypes = [vp, vp, vp, u32, C.POINTER(DmfbVecStepOut), vp]
+    lib.dmfb_vec_observe.argtypes = [vp, vp, vp, vp]
+    lib.dmfb_vec_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.dmfb_vec_get_map.argtypes = [vp, i32, vp, vp]
+    lib.dmfb_vec_set_map.argtypes = [vp, i32, vp, vp]
+    lib.dmfb_vec_zoom_lut.argtypes = [vp, vp]
+    lib.dmfb_vec_strerror.argtypes = [i32]
+    lib.dmfb_vec_strerror.restype = C.c_char_p
+    lib.dmfb_vec_last_hip_error.argtypes = []
+    lib._typed = True
+    return lib

@@ -1,0 +1,589 @@
+// dmfb_kernels.h -- device code of the vectorised DMFB environment (gfx950).
+//
+// Included by dmfb_vec_n.hip (one translation unit per droplet count N, so the 16 instantiations
+// build in parallel) and by dmfb_vec.hip (C ABI, N-independent kernels, dispatch).
+//
+// What runs here replaces, for thousands of chips at once, the reference's per-chip Python:
+//   DMFBenv.step / reset / restart / getObs          env/DMFB/dmfb.py:560-626
+//   RoutingTaskManager.moveDroplets / moveOneDroplet  env/DMFB/dmfb.py:253-359
+//   RoutingTaskManager.getOneObs                      env/DMFB/dmfb.py:395-457
+//   RoutingTaskManager.addUsage / updateHealth        env/DMFB/dmfb.py:459-471
+//   RoutingTaskManager._Generate_Start_End            env/DMFB/dmfb.py:207-226
+//
+// Design (DESIGN.md has the long form):
+//   * State is structure-of-arrays in HBM: word w of env e lives at st[w*E + e], so a wave that
+//     owns 64 consecutive envs reads/writes 256 contiguous bytes per word.
+//   * One workgroup (256 threads) owns a tile of T consecutive envs.  Wave 0 runs the
+//     transition, one lane per env; droplets are moved serially in index order inside the lane
+//     (the reference's semantics are order dependent).  Episode ends are resolved with a wave
+//     ballot; new tasks are found by all 64 lanes testing 64 rejection-sampling attempts at once.
+//   * Observations (89 % of the bytes) are assembled in LDS: the tile's rows are zero-filled with
+//     16-byte LDS stores, the few non-zero cells are scattered with byte stores, then the tile is
+//     streamed to HBM with 16-byte-per-lane coalesced stores.
+//   * Pure integer work apart from the health compare and the reward sums, which are float64
+//     so that results are bit-identical to the reference.  No MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/dmfb_vec.h"
+
+namespace dmfbk {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+// Rejection sampling is bounded so that every wave terminates: after 2^22 rejected attempts the
+// last attempt's points are kept as they are (same rule in the oracle; never hit by legal configs
+// of practical density).
+constexpr uint32_t kTaskMaxRounds = 1u << 16;
+
+enum : uint32_t { STREAM_MOVE = 1, STREAM_TASK = 2, STREAM_DEGRADE = 3, STREAM_BLOCK = 4 };
+
+struct DevCfg {
+    int W, L, fov, hf, ff, obs_len, max_step, stall, b_degrade, E, n, T;
+    uint32_t k0, k1, env_id0;
+    double per_healthy;
+};
+
+struct DevPtrs {
+    uint32_t *st;      // [NW][E] packed env records
+    uint32_t *starts;  // [NP][E] packed start cells
+    double *health;    // [E][W*L] or nullptr
+    double *degrade;   // [E][W*L]
+    uint16_t *usage;   // [E][W*L]
+    const int8_t *zoom;  // [2][511] direction zoom table
+};
+
+// ---- packed record layout -------------------------------------------------------------------
+// NP = ceil(N/2) words of positions (agent i: word i>>1, half i&1, value x | y<<8),
+// NP words of goals, then: step_count | flags<<16, cumulative constraints, rng_step, rng_ep, rng_map.
+template <int N> struct Rec {
+    static constexpr int NP = (N + 1) / 2;
+    static constexpr int W_POS = 0, W_GOAL = NP, W_STEP = 2 * NP, W_CUM = 2 * NP + 1,
+                         W_RSTEP = 2 * NP + 2, W_REP = 2 * NP + 3, W_RMAP = 2 * NP + 4, NW = 2 * NP + 5;
+};
+constexpr uint32_t FLAG_DUP = 1u;  // two droplets share a cell (only reachable through set_task)
+
+__host__ __device__ inline int rec_words(int n) { return 2 * ((n + 1) / 2) + 5; }
+
+// ---- Philox4x32-10 ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
+                                       uint32_t c3, uint32_t (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+    uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (double)(v >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ int below(uint32_t w, int n) { return (int)__umulhi(w, (uint32_t)n); }
+
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
+
+// ---- per-lane env registers -------------------------------------------------------------------
+template <int N> struct EnvR {
+    int x[N], y[N], gx[N], gy[N];
+    uint32_t step, flags, cum, rstep, rep, rmap;
+};
+
+template <int N>
+__device__ __forceinline__ void load_env(const DevPtrs &p, int E, int e, EnvR<N> &r) {
+    using R = Rec<N>;
+#pragma unroll
+    for (int w = 0; w < R::NP; ++w) {
+        uint32_t pw = p.st[(size_t)(R::W_POS + w) * E + e];
+        uint32_t gw = p.st[(size_t)(R::W_GOAL + w) * E + e];
+        r.x[2 * w] = pw & 0xff; r.y[2 * w] = (pw >> 8) & 0xff;
+        r.gx[2 * w] = gw & 0xff; r.gy[2 * w] = (gw >> 8) & 0xff;
+        if (2 * w + 1 < N) {
+            r.x[2 * w + 1] = (pw >> 16) & 0xff; r.y[2 * w + 1] = (pw >> 24) & 0xff;
+            r.gx[2 * w + 1] = (gw >> 16) & 0xff; r.gy[2 * w + 1] = (gw >> 24) & 0xff;
+        }
+    }
+    uint32_t s = p.st[(size_t)R::W_STEP * E + e];
+    r.step = s & 0xffff; r.flags = s >> 16;
+    r.cum = p.st[(size_t)R::W_CUM * E + e];
+    r.rstep = p.st[(size_t)R::W_RSTEP * E + e];
+    r.rep = p.st[(size_t)R::W_REP * E + e];
+    r.rmap = p.st[(size_t)R::W_RMAP * E + e];
+}
+
+template <int N> __device__ __forceinline__ uint32_t pack_pos(const int (&x)[N], const int (&y)[N], int w) {
+    uint32_t v = (uint32_t)x[2 * w] | ((uint32_t)y[2 * w] << 8);
+    if (2 * w + 1 < N) v |= ((uint32_t)x[2 * w + 1] << 16) | ((uint32_t)y[2 * w + 1] << 24);
+    return v;
+}
+
+template <int N>
+__device__ __forceinline__ void store_env(const DevPtrs &p, int E, int e, const EnvR<N> &r, bool with_goal) {
+    using R = Rec<N>;
+#pragma unroll
+    for (int w = 0; w < R::NP; ++w) {
+        p.st[(size_t)(R::W_POS + w) * E + e] = pack_pos<N>(r.x, r.y, w);
+        if (with_goal) p.st[(size_t)(R::W_GOAL + w) * E + e] = pack_pos<N>(r.gx, r.gy, w);
+    }
+    p.st[(size_t)R::W_STEP * E + e] = (r.step & 0xffff) | (r.flags << 16);
+    p.st[(size_t)R::W_CUM * E + e] = r.cum;
+    p.st[(size_t)R::W_RSTEP * E + e] = r.rstep;
+    p.st[(size_t)R::W_REP * E + e] = r.rep;
+    p.st[(size_t)R::W_RMAP * E + e] = r.rmap;
+}
+
+template <int N> __device__ __forceinline__ bool any_dup(const EnvR<N> &r) {
+    bool d = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) d |= (r.x[i] == r.x[j]) & (r.y[i] == r.y[j]);
+    return d;
+}
+
+// ---- task generation: _Generate_Start_End (dmfb.py:207-226) -----------------------------------
+// Executed by a FULL wave with wave-uniform (env_gid, ep).  Lane l tests attempt 64*round + l;
+// the lowest accepted attempt wins, which is exactly the first accepted attempt of a serial loop.
+// On return every lane holds the winner's 2N points: pts[b] = point 2b | point (2b+1) << 16.
+template <int N>
+__device__ __forceinline__ void gen_task_wave(const DevCfg &c, uint32_t env_gid, uint32_t ep, uint32_t (&pts)[N]) {
+    const int lane = lane_id();
+    for (uint32_t round = 0;; ++round) {
+        const bool last = round == kTaskMaxRounds - 1;  // bounded: the final attempt is kept unchecked
+        const uint32_t attempt = round * kWave + lane;
+        uint32_t mine[N];
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+            uint32_t w[4];
+            philox(c.k0, c.k1, env_gid, ep, attempt, (STREAM_TASK << 8) | (uint32_t)b, w);
+            uint32_t p0 = (uint32_t)below(w[1], c.W) | ((uint32_t)below(w[0], c.L) << 8);
+            uint32_t p1 = (uint32_t)below(w[3], c.W) | ((uint32_t)below(w[2], c.L) << 8);
+            mine[b] = p0 | (p1 << 16);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 2 * N; ++i) {
+            const uint32_t pi = (mine[i >> 1] >> (16 * (i & 1))) & 0xffff;
+            const int xi = pi & 0xff, yi = pi >> 8;
+#pragma unroll
+            for (int j = i + 1; j < 2 * N; ++j) {
+                const uint32_t pj = (mine[j >> 1] >> (16 * (j & 1))) & 0xffff;
+                const int dx = xi - (int)(pj & 0xff), dy = yi - (int)(pj >> 8);
+                ok &= (dx * dx + dy * dy > 2);
+            }
+        }
+        const unsigned long long acc = __ballot(ok) | (last ? (1ull << (kWave - 1)) : 0ull);
+        if (acc) {
+            const int win = __ffsll((long long)acc) - 1;
+#pragma unroll
+            for (int b = 0; b < N; ++b) pts[b] = (uint32_t)__shfl((int)mine[b], win, kWave);
+            return;
+        }
+    }
+}
+
+template <int N> __device__ __forceinline__ void task_to_env(const uint32_t (&pts)[N], EnvR<N> &r, int (&sx)[N], int (&sy)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t s = (pts[i >> 1] >> (16 * (i & 1))) & 0xffff;
+        const int gi = N + i;
+        const uint32_t g = (pts[gi >> 1] >> (16 * (gi & 1))) & 0xffff;
+        sx[i] = s & 0xff; sy[i] = s >> 8;
+        r.x[i] = sx[i]; r.y[i] = sy[i];
+        r.gx[i] = g & 0xff; r.gy[i] = g >> 8;
+    }
+}
+
+template <int N> __device__ __forceinline__ void store_starts(const DevPtrs &p, int E, int e, const int (&sx)[N], const int (&sy)[N]) {
+#pragma unroll
+    for (int w = 0; w < Rec<N>::NP; ++w) p.starts[(size_t)w * E + e] = pack_pos<N>(sx, sy, w);
+}
+
+// ---- health maps ------------------------------------------------------------------------------
+// updateHealth (dmfb.py:465-471) for one env, strided over `nthreads` cooperating threads.
+__device__ __forceinline__ void update_health_env(const DevPtrs &p, int cells, int e, int tid, int nthreads) {
+    const size_t base = (size_t)e * cells;
+    for (int cidx = tid; cidx < cells; cidx += nthreads) {
+        if (p.usage[base + cidx] > 50) {
+            p.health[base + cidx] = p.health[base + cidx] * p.degrade[base + cidx];
+            p.usage[base + cidx] = 0;
+        }
+    }
+}
+// _random_health_statue (dmfb.py:157-166) for one env
+__device__ __forceinline__ void gen_degrade_env(const DevCfg &c, const DevPtrs &p, int cells, int e, uint32_t rmap,
+                                                int tid, int nthreads) {
+    const size_t base = (size_t)e * cells;
+    for (int cidx = tid; cidx < cells; cidx += nthreads) {
+        double v = 1.0;
+        if (c.b_degrade) {
+            uint32_t w[4];
+            philox(c.k0, c.k1, c.env_id0 + (uint32_t)e, rmap, (uint32_t)cidx, STREAM_DEGRADE << 8, w);
+            const double d = u53(w[0], w[1]) * 0.4 + 0.6;
+            const double sel = u53(w[2], w[3]);
+            v = (sel < c.per_healthy) ? 1.0 : d;
+        }
+        p.degrade[base + cidx] = v;
+    }
+}
+
+// ---- LDS tile -----------------------------------------------------------------------------------
+struct Tile {
+    int8_t *obs;       // [T][N][obs_len], 16-byte aligned
+    uint16_t *pos;     // [T][N]
+    uint16_t *goal;    // [T][N]
+    uint8_t *flag;     // [T] per-env flag (ended / masked)
+};
+__device__ __forceinline__ size_t tile_obs_bytes(int T, int n, int obs_len) {
+    return ((size_t)T * n * obs_len + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t tile_lds_bytes(int T, int n, int obs_len) {
+    return (((size_t)T * n * obs_len + 15) & ~(size_t)15) + (size_t)T * n * 4 + (((size_t)T + 15) & ~(size_t)15);
+}
+__device__ __forceinline__ Tile carve(unsigned char *smem, int T, int n, int obs_len) {
+    Tile t;
+    t.obs = (int8_t *)smem;
+    size_t off = tile_obs_bytes(T, n, obs_len);
+    t.pos = (uint16_t *)(smem + off);
+    t.goal = t.pos + (size_t)T * n;
+    t.flag = (uint8_t *)(t.goal + (size_t)T * n);
+    return t;
+}
+
+__device__ __forceinline__ void zero_tile(const Tile &t, int bytes16, int tid, int nthreads) {
+    uint4 *p = (uint4 *)t.obs;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < bytes16; i += nthreads) p[i] = z;
+}
+
+// getOneObs (dmfb.py:395-457) for every (env, agent) row of the tile: scatter the non-zero cells.
+// Work items: [0, tv*n) rows for layers 0/1 + direction; [tv*n, tv*n*(1+fov)) boundary-band rows.
+__device__ __forceinline__ void scatter_tile(const DevCfg &c, const DevPtrs &p, const Tile &t, int tv, int tid,
+                                             int nthreads) {
+    const int n = c.n, fov = c.fov, hf = c.hf, ff = c.ff;
+    const int rows = tv * n;
+    for (int it = tid; it < rows * (1 + fov); it += nthreads) {
+        if (it < rows) {
+            const int env = it / n, i = it - env * n;
+            int8_t *row = t.obs + (size_t)it * c.obs_len;
+            const uint16_t *pp = t.pos + env * n, *gp = t.goal + env * n;
+            const int cx = pp[i] & 0xff, cy = pp[i] >> 8;
+            const int ox = cx - hf, oy = cy - hf;
+            for (int j = 0; j < n; ++j) {  // layer 0: all droplets inside the window
+                const int x = (pp[j] & 0xff) - ox, y = (pp[j] >> 8) - oy;
+                if (x >= 0 && x < fov && y >= 0 && y < fov) row[x * fov + y] = (int8_t)(j + 1);
+            }
+            for (int j = 0; j < n; ++j) {  // layer 1: clipped goals of the other visible droplets
+                const int xj = pp[j] & 0xff, yj = pp[j] >> 8;
+                if (j != i && 2 * iabs(xj - cx) < fov && 2 * iabs(yj - cy) < fov) {
+                    int x = (gp[j] & 0xff) - ox, y = (gp[j] >> 8) - oy;
+                    x = x < 0 ? 0 : (x > fov - 1 ? fov - 1 : x);
+                    y = y < 0 ? 0 : (y > fov - 1 ? fov - 1 : y);
+                    row[ff + x * fov + y] = (int8_t)(j + 1);
+                }
+            }
+            row[3 * ff] = p.zoom[(gp[i] & 0xff) - cx + 255];
+            row[3 * ff + 1] = p.zoom[511 + (gp[i] >> 8) - cy + 255];
+        } else {  // layer 2: out-of-chip bands (dmfb.py:428-439), one window row x per item
+            const int k = it - rows;
+            const int r = k / fov, x = k - r * fov;
+            const int env = r / n;
+            const uint16_t pc = t.pos[r];
+            (void)env;
+            const int cx = pc & 0xff, cy = pc >> 8;
+            const int left = hf - cx, right = hf - (c.W - 1 - cx);
+            const int up = hf - cy, down = hf - (c.L - 1 - cy);
+            const bool xb = left > 0 ? (x < left) : (right > 0 ? (x >= fov - right) : false);
+            int y0 = 0, y1 = 0;  // band of y set because of the y bounds
+            if (up > 0) { y0 = 0; y1 = up < fov ? up : fov; }
+            else if (down > 0) { y0 = fov - down < 0 ? 0 : fov - down; y1 = fov; }
+            if (xb) { y0 = 0; y1 = fov; }
+            int8_t *row = t.obs + (size_t)r * c.obs_len + 2 * ff + x * fov;
+            for (int y = y0; y < y1; ++y) row[y] = 1;
+        }
+    }
+}
+
+// stream the finished tile to HBM: 16 bytes per lane, fully coalesced
+__device__ __forceinline__ void copy_tile_out(const Tile &t, int8_t *gobs, size_t tile_off, int bytes, int tid,
+                                              int nthreads) {
+    const int n16 = bytes >> 4;
+    const uint4 *src = (const uint4 *)t.obs;
+    uint4 *dst = (uint4 *)(gobs + tile_off);
+    for (int i = tid; i < n16; i += nthreads) dst[i] = src[i];
+    for (int b = (n16 << 4) + tid; b < bytes; b += nthreads) gobs[tile_off + b] = t.obs[b];
+}
+
+template <typename T> __device__ __forceinline__ int load_action(const void *a, size_t idx) {
+    return (int)((const T *)a)[idx];
+}
+
+// ---- the fused transition kernel ------------------------------------------------------------------
+struct StepArgs {
+    const void *actions;
+    const double *uniforms;
+    uint32_t flags;
+    dmfb_vec_step_out out;
+};
+
+template <int N, bool MAPS>
+__global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int T = c.T, E = c.E;
+    const Tile t = carve(smem, T, N, c.obs_len);
+    const int tid = threadIdx.x;
+    const int tile_base = blockIdx.x * T;
+    const int tv = min(T, E - tile_base);
+    const bool want_obs = a.out.d_obs != nullptr;
+    const int cells = c.W * c.L;
+
+    if (tid >= kWave) {
+        if (want_obs) zero_tile(t, (int)(tile_obs_bytes(tv, N, c.obs_len) >> 4), tid - kWave, kBlock - kWave);
+    } else {
+        // ------------------------------------------------------------------ wave 0: one lane per env
+        // T <= 64, so lane == env slot in the tile.
+        const int lane = tid;
+        const bool active = lane < tv;
+        const int e = tile_base + (active ? lane : 0);
+        EnvR<N> r;
+        bool ended = false;
+        if (active) {
+            load_env<N>(p, E, e, r);
+            // ---- moveDroplets (dmfb.py:253-299)
+            int code[N], pastx[N], pasty[N], sta[N], dyn[N];
+            bool was_done[N];
+            r.step += 1;
+#pragma unroll
+            for (int i = 0; i < N; ++i) was_done[i] = (iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) == 0;
+            const bool dup = (r.flags & FLAG_DUP) != 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {  // moveOneDroplet (dmfb.py:325-359), strictly in index order
+                const int x0 = r.x[i], y0 = r.y[i];
+                const int old = iabs(x0 - r.gx[i]) + iabs(y0 - r.gy[i]);
+                pastx[i] = x0; pasty[i] = y0;
+                int act;
+                const size_t ai = (size_t)e * N + i;
+                if (a.flags & DMFB_ACT_I8) act = load_action<int8_t>(a.actions, ai);
+                else if (a.flags & DMFB_ACT_I64) act = load_action<long long>(a.actions, ai);
+                else act = load_action<int32_t>(a.actions, ai);
+                if (c.stall && old == 0) {
+                    code[i] = 0;
+                } else {
+                    bool mv = true;
+                    if (MAPS || a.uniforms) {
+                        double u;
+                        if (a.uniforms) u = a.uniforms[ai];
+                        else {
+                            uint32_t w[4];
+                            philox(c.k0, c.k1, c.env_id0 + (uint32_t)e, r.rstep, (uint32_t)i, STREAM_MOVE << 8, w);
+                            u = u53(w[0], w[1]);
+                        }
+                        double prob = 1.0;
+                        if (MAPS) prob = p.health[(size_t)e * cells + x0 * c.L + y0];  // getMoveProb (dmfb.py:361-363)
+                        mv = (u <= prob);
+                    }
+                    if (mv) {
+                        int nx = x0 + (act == 1) - (act == 2), ny = y0 + (act == 4) - (act == 3);  // Droplet.move (dmfb.py:103-124)
+                        nx = nx > c.W - 1 ? c.W - 1 : (nx < 0 ? 0 : nx);
+                        ny = ny > c.L - 1 ? c.L - 1 : (ny < 0 ? 0 : ny);
+                        r.x[i] = nx; r.y[i] = ny;
+                        bool clash = false;  // _isinvalidaction (dmfb.py:310-323)
+                        if (dup) clash = any_dup<N>(r);
+                        else {
+#pragma unroll
+                            for (int j = 0; j < N; ++j)
+                                if (j != i) clash |= (r.x[j] == nx) & (r.y[j] == ny);
+                        }
+                        if (clash) { r.x[i] = x0; r.y[i] = y0; }
+                    }
+                    const int nd = iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i]);
+                    code[i] = (nd == old && old == 0) ? 1 : (nd == old && act == 0) ? 2 : (nd < old) ? 1 : 3;
+                }
+            }
+            r.rstep += 1;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { sta[i] = 0; dyn[i] = 0; }
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    if (j > i) {  // comflic_static (dmfb.py:254-261)
+                        const bool near = (iabs(r.x[i] - r.x[j]) <= 1) & (iabs(r.y[i] - r.y[j]) <= 1);
+                        sta[i] += near; sta[j] += near;
+                    }
+                    if (j != i) {  // comflic_dynamic (dmfb.py:263-271)
+                        const bool near = (iabs(pastx[i] - r.x[j]) <= 1) & (iabs(pasty[i] - r.y[j]) <= 1);
+                        dyn[i] += near; dyn[j] += near;
+                    }
+                }
+            int constraints = 0;
+            bool all_done = true;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                constraints += sta[i] + dyn[i];
+                all_done &= (iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) == 0;
+            }
+            // rewards: ((base - 2*sta) - 2*dy), 0 if it was done, +10, +10  (dmfb.py:288-296)
+            double rew[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double base = code[i] == 0 ? 0.0 : code[i] == 1 ? -0.1 : code[i] == 2 ? -0.25 : -0.4;
+                double v = (base - (double)(2 * sta[i])) - (double)(2 * dyn[i]);
+                if (c.stall && was_done[i]) v = 0.0;
+                if (all_done) {
+                    v = v + 10.0;
+                    if (constraints == 0) v = v + 10.0;
+                }
+                rew[i] = v;
+            }
+            if (MAPS && (a.flags & DMFB_STEP_RECORD)) {  // addUsage (dmfb.py:459-463)
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    if ((iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) != 0)
+                        p.usage[(size_t)e * cells + r.x[i] * c.L + r.y[i]] += 1;
+            }
+            r.cum += (uint32_t)constraints;
+            const bool in_time = (int)r.step < c.max_step;  // DMFBenv.step (dmfb.py:577-585)
+            const bool success = in_time && all_done && r.cum == 0;
+            bool term = true;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const bool d = in_time ? ((iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) == 0) : true;
+                term &= d;
+                if (a.out.d_dones) a.out.d_dones[(size_t)e * N + i] = (uint8_t)d;
+                if (a.out.d_rewards) a.out.d_rewards[(size_t)e * N + i] = rew[i];
+            }
+            if (a.out.d_constraints) a.out.d_constraints[e] = constraints;
+            if (a.out.d_success) a.out.d_success[e] = (uint8_t)success;
+            if (a.out.d_terminated) a.out.d_terminated[e] = (uint8_t)term;
+            if (a.out.d_team_reward) {  // np.sum(list)/n: numpy pairwise order (rollout.py:33)
+                double s;
+                if constexpr (N < 8) {
+                    s = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) s = s + rew[i];
+                } else {
+                    double q[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) q[j] = rew[j];
+                    constexpr int M = N - (N % 8);
+#pragma unroll
+                    for (int i = 8; i < M; i += 8)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) q[j] = q[j] + rew[i + j];
+                    s = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+#pragma unroll
+                    for (int i = M; i < N; ++i) s = s + rew[i];
+                }
+                a.out.d_team_reward[e] = s / (double)N;
+            }
+            if (dup) r.flags = any_dup<N>(r) ? (r.flags | FLAG_DUP) : (r.flags & ~FLAG_DUP);
+            ended = term && (a.flags & DMFB_STEP_AUTORESET);
+        }
+        // ---- episode boundary inside the launch: reset(new=False) for the lanes that ended
+        unsigned long long m = __ballot(ended);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t gid = c.env_id0 + (uint32_t)(tile_base + src);
+            const uint32_t ep = (uint32_t)__shfl((int)r.rep, src, kWave);
+            uint32_t pts[N];
+            gen_task_wave<N>(c, gid, ep, pts);
+            if (lane == src) {
+                int sx[N], sy[N];
+                task_to_env<N>(pts, r, sx, sy);
+                store_starts<N>(p, E, e, sx, sy);
+                r.rep += 1; r.step = 0; r.cum = 0; r.flags = 0;
+            }
+        }
+        if (active) {
+            store_env<N>(p, E, e, r, ended);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                t.pos[lane * N + i] = (uint16_t)(r.x[i] | (r.y[i] << 8));
+                t.goal[lane * N + i] = (uint16_t)(r.gx[i] | (r.gy[i] << 8));
+            }
+            t.flag[lane] = (uint8_t)ended;
+        }
+    }
+    __syncthreads();
+    if (MAPS && (a.flags & DMFB_STEP_AUTORESET)) {  // updateHealth for the envs that were reset (dmfb.py:182-183)
+        for (int s = 0; s < tv; ++s)
+            if (t.flag[s]) update_health_env(p, cells, tile_base + s, tid, kBlock);
+    }
+    if (!want_obs) return;
+    scatter_tile(c, p, t, tv, tid, kBlock);
+    __syncthreads();
+    copy_tile_out(t, a.out.d_obs, (size_t)tile_base * N * c.obs_len, tv * N * c.obs_len, tid, kBlock);
+}
+
+// ---- reset / restart / init: one wave per env -------------------------------------------------------
+// mode 0: reset(new=False)  1: reset(new=True)  2: restart()  3: create (first task + fresh maps)
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_reset(DevCfg c, DevPtrs p, const uint8_t *mask, int mode) {
+    using R = Rec<N>;
+    const int E = c.E;
+    const int e = blockIdx.x * (kBlock / kWave) + (int)(threadIdx.x / kWave);
+    if (e >= E) return;
+    if (mask && !mask[e]) return;
+    const int lane = lane_id();
+    const int cells = c.W * c.L;
+    if (mode == 2) {  // restartforall (dmfb.py:185-190) + counters (dmfb.py:599-605)
+        if (lane == 0) {
+            bool d = false;
+            uint32_t sw[R::NP];
+#pragma unroll
+            for (int w = 0; w < R::NP; ++w) {
+                sw[w] = p.starts[(size_t)w * E + e];
+                p.st[(size_t)(R::W_POS + w) * E + e] = sw[w];
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = i + 1; j < N; ++j)
+                    d |= ((sw[i >> 1] >> (16 * (i & 1))) & 0xffff) == ((sw[j >> 1] >> (16 * (j & 1))) & 0xffff);
+            p.st[(size_t)R::W_STEP * E + e] = d ? (FLAG_DUP << 16) : 0u;
+            p.st[(size_t)R::W_CUM * E + e] = 0;
+        }
+        return;
+    }
+    uint32_t rep = mode == 3 ? 0u : p.st[(size_t)R::W_REP * E + e];
+    uint32_t rmap = mode == 3 ? 0u : p.st[(size_t)R::W_RMAP * E + e];
+    uint32_t pts[N];
+    gen_task_wave<N>(c, c.env_id0 + (uint32_t)e, rep, pts);
+    if (lane == 0) {
+        EnvR<N> r;
+        int sx[N], sy[N];
+        task_to_env<N>(pts, r, sx, sy);
+        store_starts<N>(p, E, e, sx, sy);
+        r.step = 0; r.flags = 0; r.cum = 0;
+        r.rstep = mode == 3 ? 0u : p.st[(size_t)R::W_RSTEP * E + e];
+        r.rep = rep + 1;
+        r.rmap = rmap + ((mode == 1 || mode == 3) && p.health && c.b_degrade ? 1u : 0u);
+        store_env<N>(p, E, e, r, true);
+    }
+    if (p.health) {
+        if (mode == 0) {
+            update_health_env(p, cells, e, lane, kWave);
+        } else {
+            const size_t base = (size_t)e * cells;
+            for (int cidx = lane; cidx < cells; cidx += kWave) { p.health[base + cidx] = 1.0; p.usage[base + cidx] = 0; }
+            gen_degrade_env(c, p, cells, e, rmap, lane, kWave);
+        }
+    }
+}
+
+
+// ---- per-N launchers: declared here, defined (explicitly specialised) in dmfb_vec_n.hip -------------
+template <int N>
+hipError_t launch_step_n(const DevCfg &c, const DevPtrs &p, const StepArgs &a, int grid, size_t lds, hipStream_t s);
+template <int N>
+hipError_t launch_reset_n(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int mode, int grid, hipStream_t s);
+
+}  // namespace dmfbk

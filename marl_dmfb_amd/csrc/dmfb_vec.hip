@@ -1,0 +1,411 @@
+// dmfb_vec.hip -- C ABI (include/dmfb_vec.h) of the vectorised DMFB environment, the
+// N-independent kernels (observation, task/state/map accessors) and the dispatch to the per-N
+// transition/reset kernels built from dmfb_vec_n.hip.  Device code: dmfb_kernels.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "dmfb_kernels.h"
+
+using namespace dmfbk;
+
+namespace {
+
+// ---- standalone observation kernel (getObs after reset/restart/set_task) ---------------------------
+__global__ __launch_bounds__(kBlock) void k_observe(DevCfg c, DevPtrs p, const uint8_t *mask, int8_t *gobs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int T = c.T, E = c.E, n = c.n;
+    const Tile t = carve(smem, T, n, c.obs_len);
+    const int tid = threadIdx.x;
+    const int tile_base = blockIdx.x * T;
+    const int tv = min(T, E - tile_base);
+    const int np = (n + 1) / 2;
+    bool all = true, any = true;
+    if (mask) {
+        int cnt = 0;
+        for (int s = 0; s < tv; ++s) cnt += mask[tile_base + s] != 0;
+        all = cnt == tv; any = cnt > 0;
+    }
+    if (!any) return;
+    for (int it = tid; it < tv * n; it += kBlock) {
+        const int s = it / n, i = it - s * n;
+        const int e = tile_base + s;
+        const uint32_t pw = p.st[(size_t)(i >> 1) * E + e], gw = p.st[(size_t)(np + (i >> 1)) * E + e];
+        t.pos[it] = (uint16_t)(pw >> (16 * (i & 1)));
+        t.goal[it] = (uint16_t)(gw >> (16 * (i & 1)));
+    }
+    zero_tile(t, (int)(tile_obs_bytes(tv, n, c.obs_len) >> 4), tid, kBlock);
+    __syncthreads();
+    scatter_tile(c, p, t, tv, tid, kBlock);
+    __syncthreads();
+    const int row_bytes = n * c.obs_len;
+    if (all) {
+        copy_tile_out(t, gobs, (size_t)tile_base * row_bytes, tv * row_bytes, tid, kBlock);
+    } else {
+        for (int s = 0; s < tv; ++s)
+            if (mask[tile_base + s])
+                for (int b = tid; b < row_bytes; b += kBlock)
+                    gobs[(size_t)(tile_base + s) * row_bytes + b] = t.obs[(size_t)s * row_bytes + b];
+    }
+}
+
+// ---- small utility kernels -----------------------------------------------------------------------
+__global__ void k_set_task(DevCfg c, DevPtrs p, const int32_t *starts, const int32_t *ends) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= c.E) return;
+    const int n = c.n, np = (n + 1) / 2, E = c.E;
+    bool dup = false;
+    for (int w = 0; w < np; ++w) {
+        uint32_t sw = 0, gw = 0;
+        for (int h = 0; h < 2 && 2 * w + h < n; ++h) {
+            const size_t k = ((size_t)e * n + 2 * w + h) * 2;
+            sw |= ((uint32_t)(starts[k] & 0xff) | ((uint32_t)(starts[k + 1] & 0xff) << 8)) << (16 * h);
+            gw |= ((uint32_t)(ends[k] & 0xff) | ((uint32_t)(ends[k + 1] & 0xff) << 8)) << (16 * h);
+        }
+        p.starts[(size_t)w * E + e] = sw;
+        p.st[(size_t)w * E + e] = sw;
+        p.st[(size_t)(np + w) * E + e] = gw;
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            const size_t a = ((size_t)e * n + i) * 2, b = ((size_t)e * n + j) * 2;
+            dup |= (starts[a] == starts[b]) && (starts[a + 1] == starts[b + 1]);
+        }
+    p.st[(size_t)(2 * np) * E + e] = dup ? (FLAG_DUP << 16) : 0u;
+    p.st[(size_t)(2 * np + 1) * E + e] = 0;
+}
+
+__global__ void k_get_task(DevCfg c, DevPtrs p, int32_t *starts, int32_t *ends) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= c.E) return;
+    const int n = c.n, np = (n + 1) / 2, E = c.E;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t s = (p.starts[(size_t)(i >> 1) * E + e] >> (16 * (i & 1))) & 0xffff;
+        const uint32_t g = (p.st[(size_t)(np + (i >> 1)) * E + e] >> (16 * (i & 1))) & 0xffff;
+        const size_t k = ((size_t)e * n + i) * 2;
+        if (starts) { starts[k] = s & 0xff; starts[k + 1] = s >> 8; }
+        if (ends) { ends[k] = g & 0xff; ends[k + 1] = g >> 8; }
+    }
+}
+
+__global__ void k_get_state(DevCfg c, DevPtrs p, int32_t *pos, int32_t *dist, int32_t *step_count, int64_t *cons) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= c.E) return;
+    const int n = c.n, np = (n + 1) / 2, E = c.E;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t s = (p.st[(size_t)(i >> 1) * E + e] >> (16 * (i & 1))) & 0xffff;
+        const uint32_t g = (p.st[(size_t)(np + (i >> 1)) * E + e] >> (16 * (i & 1))) & 0xffff;
+        const int x = s & 0xff, y = s >> 8, gx = g & 0xff, gy = g >> 8;
+        if (pos) { pos[((size_t)e * n + i) * 2] = x; pos[((size_t)e * n + i) * 2 + 1] = y; }
+        if (dist) dist[(size_t)e * n + i] = iabs(x - gx) + iabs(y - gy);
+    }
+    if (step_count) step_count[e] = (int32_t)(p.st[(size_t)(2 * np) * E + e] & 0xffff);
+    if (cons) cons[e] = (int64_t)p.st[(size_t)(2 * np + 1) * E + e];
+}
+
+__global__ void k_get_map(size_t total, const double *health, const double *degrade, const uint16_t *usage, int which,
+                          double *out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    out[i] = which == DMFB_MAP_HEALTH ? health[i] : which == DMFB_MAP_DEGRADE ? degrade[i] : (double)usage[i];
+}
+__global__ void k_set_map(size_t total, double *health, double *degrade, uint16_t *usage, int which, const double *in) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (which == DMFB_MAP_HEALTH) health[i] = in[i];
+    else if (which == DMFB_MAP_DEGRADE) degrade[i] = in[i];
+    else usage[i] = (uint16_t)in[i];
+}
+
+thread_local int g_last_hip = 0;
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) { g_last_hip = (int)_e; return DMFB_ERR_HIP; } \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+        if (prev == dev) prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// python round(): half-to-even on the double value (dmfb.py:444-453)
+int zoom_one(int d, int hf, int size) {
+    if (std::abs(d) > hf) {
+        const double scale = (double)(size - hf) / (double)(10 - hf);
+        if (d > 0) return (int)std::nearbyint((double)(d - hf) / scale) + hf;
+        return (int)std::nearbyint((double)(d + hf) / scale) - hf;
+    }
+    return d;
+}
+
+}  // namespace
+
+struct dmfb_vec {
+    dmfb_vec_config cfg;
+    DevCfg dc;
+    DevPtrs dp;
+    int8_t zoom_host[2 * 511];
+    int8_t *zoom_dev = nullptr;
+    size_t bytes = 0;
+    int T_step = 16;
+};
+
+namespace {
+
+int pick_tile(const dmfb_vec *h) {
+    // T is a multiple of 16 (keeps every tile's obs offset 16-byte aligned), at most 64 (wave 0 owns
+    // one env per lane), small enough that >= 4 workgroups fit a CU's 160 KiB LDS, and small enough
+    // that the grid still covers the 256 CUs when the batch is small.
+    const int row = h->cfg.n_agents * h->dc.obs_len;
+    int T = 64;
+    while (T > 16 && (size_t)T * row > 40 * 1024) T -= 16;
+    while (T > 16 && (h->cfg.n_envs + T - 1) / T < 1024) T -= 16;
+    return T;
+}
+
+template <int N> int step_n(dmfb_vec *h, const StepArgs &a, hipStream_t s) {
+    const int T = h->dc.T;
+    HIP_TRY(launch_step_n<N>(h->dc, h->dp, a, (h->cfg.n_envs + T - 1) / T, tile_lds_bytes(T, N, h->dc.obs_len), s));
+    return DMFB_OK;
+}
+template <int N> int reset_n(dmfb_vec *h, const uint8_t *mask, int mode, hipStream_t s) {
+    HIP_TRY(launch_reset_n<N>(h->dc, h->dp, mask, mode, (h->cfg.n_envs + (kBlock / kWave) - 1) / (kBlock / kWave), s));
+    return DMFB_OK;
+}
+
+#define DISPATCH_N(n, FN, ...)                                  \
+    switch (n) {                                                \
+    case 1: return FN<1>(__VA_ARGS__);                          \
+    case 2: return FN<2>(__VA_ARGS__);                          \
+    case 3: return FN<3>(__VA_ARGS__);                          \
+    case 4: return FN<4>(__VA_ARGS__);                          \
+    case 5: return FN<5>(__VA_ARGS__);                          \
+    case 6: return FN<6>(__VA_ARGS__);                          \
+    case 7: return FN<7>(__VA_ARGS__);                          \
+    case 8: return FN<8>(__VA_ARGS__);                          \
+    case 9: return FN<9>(__VA_ARGS__);                          \
+    case 10: return FN<10>(__VA_ARGS__);                        \
+    case 11: return FN<11>(__VA_ARGS__);                        \
+    case 12: return FN<12>(__VA_ARGS__);                        \
+    case 13: return FN<13>(__VA_ARGS__);                        \
+    case 14: return FN<14>(__VA_ARGS__);                        \
+    case 15: return FN<15>(__VA_ARGS__);                        \
+    case 16: return FN<16>(__VA_ARGS__);                        \
+    default: return DMFB_ERR_UNSUPPORTED;                       \
+    }
+
+int launch_step(dmfb_vec *h, const StepArgs &a, hipStream_t s) { DISPATCH_N(h->cfg.n_agents, step_n, h, a, s) }
+int launch_reset(dmfb_vec *h, const uint8_t *mask, int mode, hipStream_t s) {
+    DISPATCH_N(h->cfg.n_agents, reset_n, h, mask, mode, s)
+}
+
+int launch_observe(const dmfb_vec *h, const uint8_t *mask, int8_t *obs, hipStream_t s) {
+    const int T = h->dc.T;
+    const int grid = (h->cfg.n_envs + T - 1) / T;
+    const size_t lds = tile_lds_bytes(T, h->cfg.n_agents, h->dc.obs_len);
+    hipLaunchKernelGGL(k_observe, dim3(grid), dim3(kBlock), lds, s, h->dc, h->dp, mask, obs);
+    HIP_TRY(hipGetLastError());
+    return DMFB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmfb_vec_check_config(const dmfb_vec_config *c) {
+    if (!c) return DMFB_ERR_BAD_ARG;
+    if (c->width < 5 || c->length < 5) return DMFB_ERR_CHIP_TOO_SMALL;
+    if (c->n_agents <= 0) return DMFB_ERR_NO_AGENTS;
+    if (c->fov > (c->width < c->length ? c->width : c->length)) return DMFB_ERR_FOV_TOO_LARGE;
+    if (c->n_agents > (int)((c->width + 1) * (c->length + 1) / 9)) return DMFB_ERR_TOO_MANY_DROPLETS;
+    if (c->n_agents > DMFB_MAX_AGENTS || c->width > DMFB_MAX_DIM || c->length > DMFB_MAX_DIM || c->fov < 1 ||
+        c->n_blocks != 0)
+        return DMFB_ERR_UNSUPPORTED;
+    if (c->n_envs <= 0) return DMFB_ERR_BAD_ARG;
+    if (tile_lds_bytes(16, c->n_agents, 3 * c->fov * c->fov + 2) > 64 * 1024) return DMFB_ERR_UNSUPPORTED;
+    return DMFB_OK;
+}
+
+int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
+    if (!out) return DMFB_ERR_BAD_ARG;
+    int rc = dmfb_vec_check_config(cfg);
+    if (rc) return rc;
+    DeviceGuard g(cfg->device);
+    if (!g.ok) { g_last_hip = (int)hipErrorInvalidDevice; return DMFB_ERR_HIP; }
+    dmfb_vec *h = new (std::nothrow) dmfb_vec();
+    if (!h) return DMFB_ERR_BAD_ARG;
+    h->cfg = *cfg;
+    DevCfg &d = h->dc;
+    d.W = cfg->width; d.L = cfg->length; d.fov = cfg->fov; d.hf = cfg->fov / 2; d.ff = cfg->fov * cfg->fov;
+    d.obs_len = 3 * d.ff + 2; d.max_step = 2 * (cfg->width + cfg->length);
+    d.stall = cfg->stall != 0; d.b_degrade = cfg->b_degrade != 0; d.E = cfg->n_envs; d.n = cfg->n_agents;
+    d.k0 = (uint32_t)cfg->seed; d.k1 = (uint32_t)(cfg->seed >> 32); d.env_id0 = cfg->env_id0;
+    d.per_healthy = 1.0 - cfg->per_degrade;
+    const int E = cfg->n_envs, n = cfg->n_agents;
+    const size_t cells = (size_t)cfg->width * cfg->length;
+    const size_t st_bytes = (size_t)rec_words(n) * E * 4, starts_bytes = (size_t)((n + 1) / 2) * E * 4;
+    hipStream_t s = (hipStream_t)stream;
+    auto fail = [&](int code) { dmfb_vec_destroy(h); return code; };
+    memset(&h->dp, 0, sizeof(h->dp));
+    if (hipMalloc(&h->dp.st, st_bytes) != hipSuccess) return fail(DMFB_ERR_HIP);
+    if (hipMalloc(&h->dp.starts, starts_bytes) != hipSuccess) return fail(DMFB_ERR_HIP);
+    h->bytes = st_bytes + starts_bytes;
+    if (cfg->b_degrade || cfg->with_maps) {
+        if (hipMalloc(&h->dp.health, cells * E * 8) != hipSuccess) return fail(DMFB_ERR_HIP);
+        if (hipMalloc(&h->dp.degrade, cells * E * 8) != hipSuccess) return fail(DMFB_ERR_HIP);
+        if (hipMalloc(&h->dp.usage, cells * E * 2) != hipSuccess) return fail(DMFB_ERR_HIP);
+        h->bytes += cells * E * 18;
+    }
+    for (int dd = -255; dd <= 255; ++dd) {
+        int zx = dd, zy = dd;
+        if (d.hf != 10) { zx = zoom_one(dd, d.hf, d.W); zy = zoom_one(dd, d.hf, d.L); }
+        h->zoom_host[dd + 255] = (int8_t)zx;
+        h->zoom_host[511 + dd + 255] = (int8_t)zy;
+    }
+    if (hipMalloc(&h->zoom_dev, sizeof(h->zoom_host)) != hipSuccess) return fail(DMFB_ERR_HIP);
+    h->bytes += sizeof(h->zoom_host);
+    if (hipMemcpyAsync(h->zoom_dev, h->zoom_host, sizeof(h->zoom_host), hipMemcpyHostToDevice, s) != hipSuccess)
+        return fail(DMFB_ERR_HIP);
+    h->dp.zoom = h->zoom_dev;
+    if (hipMemsetAsync(h->dp.st, 0, st_bytes, s) != hipSuccess) return fail(DMFB_ERR_HIP);
+    d.T = pick_tile(h);
+    rc = launch_reset(h, nullptr, 3, s);
+    if (rc) return fail(rc);
+    // the zoom table upload reads host memory owned by the handle: make it safe to use right away
+    if (hipStreamSynchronize(s) != hipSuccess) return fail(DMFB_ERR_HIP);
+    *out = h;
+    return DMFB_OK;
+}
+
+int dmfb_vec_destroy(dmfb_vec *h) {
+    if (!h) return DMFB_OK;
+    DeviceGuard g(h->cfg.device);
+    (void)hipFree(h->dp.st); (void)hipFree(h->dp.starts); (void)hipFree(h->dp.health);
+    (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage); (void)hipFree(h->zoom_dev);
+    delete h;
+    return DMFB_OK;
+}
+
+size_t dmfb_vec_state_bytes(const dmfb_vec *h) { return h ? h->bytes : 0; }
+int dmfb_vec_obs_len(const dmfb_vec *h) { return h ? h->dc.obs_len : DMFB_ERR_BAD_ARG; }
+int dmfb_vec_max_step(const dmfb_vec *h) { return h ? h->dc.max_step : DMFB_ERR_BAD_ARG; }
+int dmfb_vec_n_envs(const dmfb_vec *h) { return h ? h->cfg.n_envs : DMFB_ERR_BAD_ARG; }
+int dmfb_vec_n_agents(const dmfb_vec *h) { return h ? h->cfg.n_agents : DMFB_ERR_BAD_ARG; }
+
+int dmfb_vec_reset(dmfb_vec *h, const uint8_t *d_mask, int new_flag, int8_t *d_obs, void *stream) {
+    if (!h) return DMFB_ERR_BAD_ARG;
+    DeviceGuard g(h->cfg.device);
+    int rc = launch_reset(h, d_mask, new_flag ? 1 : 0, (hipStream_t)stream);
+    if (rc || !d_obs) return rc;
+    return launch_observe(h, d_mask, d_obs, (hipStream_t)stream);
+}
+
+int dmfb_vec_restart(dmfb_vec *h, const uint8_t *d_mask, int8_t *d_obs, void *stream) {
+    if (!h) return DMFB_ERR_BAD_ARG;
+    DeviceGuard g(h->cfg.device);
+    int rc = launch_reset(h, d_mask, 2, (hipStream_t)stream);
+    if (rc || !d_obs) return rc;
+    return launch_observe(h, d_mask, d_obs, (hipStream_t)stream);
+}
+
+int dmfb_vec_set_task(dmfb_vec *h, const int32_t *d_starts, const int32_t *d_ends, void *stream) {
+    if (!h || !d_starts || !d_ends) return DMFB_ERR_BAD_ARG;
+    DeviceGuard g(h->cfg.device);
+    hipLaunchKernelGGL(k_set_task, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dc, h->dp,
+                       d_starts, d_ends);
+    HIP_TRY(hipGetLastError());
+    return DMFB_OK;
+}
+
+int dmfb_vec_get_task(const dmfb_vec *h, int32_t *d_starts, int32_t *d_ends, void *stream) {
+    if (!h) return DMFB_ERR_BAD_ARG;
+    DeviceGuard g(h->cfg.device);
+    hipLaunchKernelGGL(k_get_task, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dc, h->dp,
+                       d_starts, d_ends);
+    HIP_TRY(hipGetLastError());
+    return DMFB_OK;
+}
+
+int dmfb_vec_step(dmfb_vec *h, const void *d_actions, const double *d_uniforms, uint32_t flags,
+                  const dmfb_vec_step_out *out, void *stream) {
+    if (!h || !d_actions || !out) return DMFB_ERR_BAD_ARG;
+    DeviceGuard g(h->cfg.device);
+    StepArgs a;
+    a.actions = d_actions; a.uniforms = d_uniforms; a.flags = flags; a.out = *out;
+    return launch_step(h, a, (hipStream_t)stream);
+}
+
+int dmfb_vec_observe(const dmfb_vec *h, const uint8_t *d_mask, int8_t *d_obs, void *stream) {
+    if (!h || !d_obs) return DMFB_ERR_BAD_ARG;
+    DeviceGuard g(h->cfg.device);
+    return launch_observe(h, d_mask, d_obs, (hipStream_t)stream);
+}
+
+int dmfb_vec_get_state(const dmfb_vec *h, int32_t *d_pos, int32_t *d_dist, int32_t *d_step_count,
+                       int64_t *d_constraints, void *stream) {
+    if (!h) return DMFB_ERR_BAD_ARG;
+    DeviceGuard g(h->cfg.device);
+    hipLaunchKernelGGL(k_get_state, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dc, h->dp,
+                       d_pos, d_dist, d_step_count, d_constraints);
+    HIP_TRY(hipGetLastError());
+    return DMFB_OK;
+}
+
+int dmfb_vec_get_map(const dmfb_vec *h, int which, double *d_buf, void *stream) {
+    if (!h || !d_buf || which < 0 || which > 2) return DMFB_ERR_BAD_ARG;
+    if (!h->dp.health) return DMFB_ERR_NO_MAPS;
+    DeviceGuard g(h->cfg.device);
+    const size_t total = (size_t)h->cfg.n_envs * h->cfg.width * h->cfg.length;
+    hipLaunchKernelGGL(k_get_map, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
+                       h->dp.health, h->dp.degrade, h->dp.usage, which, d_buf);
+    HIP_TRY(hipGetLastError());
+    return DMFB_OK;
+}
+
+int dmfb_vec_set_map(dmfb_vec *h, int which, const double *d_buf, void *stream) {
+    if (!h || !d_buf || which < 0 || which > 2) return DMFB_ERR_BAD_ARG;
+    if (!h->dp.health) return DMFB_ERR_NO_MAPS;
+    DeviceGuard g(h->cfg.device);
+    const size_t total = (size_t)h->cfg.n_envs * h->cfg.width * h->cfg.length;
+    hipLaunchKernelGGL(k_set_map, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
+                       h->dp.health, h->dp.degrade, h->dp.usage, which, d_buf);
+    HIP_TRY(hipGetLastError());
+    return DMFB_OK;
+}
+
+int dmfb_vec_zoom_lut(const dmfb_vec *h, int8_t *host_out) {
+    if (!h || !host_out) return DMFB_ERR_BAD_ARG;
+    memcpy(host_out, h->zoom_host, sizeof(h->zoom_host));
+    return DMFB_OK;
+}
+
+const char *dmfb_vec_strerror(int code) {
+    switch (code) {
+    case DMFB_OK: return "ok";
+    case DMFB_ERR_BAD_ARG: return "bad argument";
+    case DMFB_ERR_FOV_TOO_LARGE: return "Fov is too large";
+    case DMFB_ERR_TOO_MANY_DROPLETS: return "Too many droplets for DMFB";
+    case DMFB_ERR_CHIP_TOO_SMALL: return "width >= 5 and length >= 5 required";
+    case DMFB_ERR_NO_AGENTS: return "n_agents > 0 required";
+    case DMFB_ERR_UNSUPPORTED: return "configuration outside the build limits";
+    case DMFB_ERR_BAD_ACTION: return "action is illegal";
+    case DMFB_ERR_NO_MAPS: return "handle was created without health/usage/degrade maps";
+    case DMFB_ERR_HIP: return "HIP runtime error";
+    default: return "unknown error";
+    }
+}
+
+int dmfb_vec_last_hip_error(void) { return g_last_hip; }
+
+}  // extern "C"

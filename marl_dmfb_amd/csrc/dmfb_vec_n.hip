@@ -1,0 +1,26 @@
+// dmfb_vec_n.hip -- instantiates the transition and reset kernels for ONE droplet count
+// (compile with -DDMFB_TU_N=<n>); see dmfb_kernels.h.
+#include "dmfb_kernels.h"
+
+#ifndef DMFB_TU_N
+#error "compile with -DDMFB_TU_N=<droplet count>"
+#endif
+
+namespace dmfbk {
+
+template <>
+hipError_t launch_step_n<DMFB_TU_N>(const DevCfg &c, const DevPtrs &p, const StepArgs &a, int grid, size_t lds,
+                                    hipStream_t s) {
+    if (p.health) hipLaunchKernelGGL((k_step<DMFB_TU_N, true>), dim3(grid), dim3(kBlock), lds, s, c, p, a);
+    else hipLaunchKernelGGL((k_step<DMFB_TU_N, false>), dim3(grid), dim3(kBlock), lds, s, c, p, a);
+    return hipGetLastError();
+}
+
+template <>
+hipError_t launch_reset_n<DMFB_TU_N>(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int mode, int grid,
+                                     hipStream_t s) {
+    hipLaunchKernelGGL((k_reset<DMFB_TU_N>), dim3(grid), dim3(kBlock), 0, s, c, p, mask, mode);
+    return hipGetLastError();
+}
+
+}  // namespace dmfbk

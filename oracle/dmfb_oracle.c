@@ -29,6 +29,7 @@
 
 #define DMFB_MAX_AGENTS 32
 #define DMFB_MAX_BLOCKS 64
+#define DMFB_TASK_MAX_ATTEMPTS (1u << 22)
 
 /* error codes (mirrors include/dmfb_vec.h) */
 #define DMFB_OK 0
@@ -201,7 +202,7 @@ static void gen_start_end(dmfb_oracle *o, dmfb_env *e) {
                 int dx = px[i] - px[j], dy = py[i] - py[j];
                 if (dx * dx + dy * dy <= 2) { ok = 0; break; }
             }
-        if (ok) break;
+        if (ok || attempt == DMFB_TASK_MAX_ATTEMPTS - 1) break; /* bounded like the kernels */
     }
     for (int i = 0; i < n; ++i) {
         e->sx[i] = px[i]; e->sy[i] = py[i];

@@ -1,0 +1,54 @@
+"""CPU-side checks of the C ABI: the in-tree HIP library loads without a GPU, exports every
+symbol include/dmfb_vec.h declares, and the config guards return the reference's error classes."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from marl_dmfb_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, 'include', header)).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(dmfb_vec_[a-z_0-9]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.dmfb_vec()
+    names = _declared('dmfb_vec.h')
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.DMFB_VEC_SYMBOLS) == names
+
+
+def _cfg(**kw):
+    base = dict(width=10, length=10, n_agents=4, n_blocks=0, fov=9, stall=1, b_degrade=0, with_maps=0,
+                per_degrade=0.1, n_envs=8, env_id0=0, seed=0, device=0)
+    base.update(kw)
+    return _lib.DmfbVecConfig(**base)
+
+
+@pytest.mark.parametrize('kw,code', [
+    ({}, 0),
+    ({'fov': 11}, -2),                      # RuntimeError('Fov is too large')        dmfb.py:139-140
+    ({'n_agents': 14}, -3),                 # TypeError('Too many droplets for DMFB') dmfb.py:144-146
+    ({'width': 4}, -4),                     # assert width >= 5                        dmfb.py:489
+    ({'n_agents': 0}, -5),                  # assert n_agents > 0                      dmfb.py:490
+    ({'width': 50, 'length': 50, 'n_agents': 17}, -6),
+    ({'n_envs': 0}, -1),
+])
+def test_check_config_codes(kw, code):
+    lib = _lib.dmfb_vec()
+    c = _cfg(**kw)
+    assert lib.dmfb_vec_check_config(C.byref(c)) == code
+
+
+def test_strerror():
+    lib = _lib.dmfb_vec()
+    assert lib.dmfb_vec_strerror(-2) == b'Fov is too large'
+    assert lib.dmfb_vec_strerror(-3) == b'Too many droplets for DMFB'
