@@ -21,6 +21,10 @@ def load(name):
         raise HipLibraryMissing(
             '%s not found: build the HIP extension first (python -c "import __graft_entry__ as g; g.build()" '
             'or make -C marl_dmfb_amd/csrc). There is no CPU fallback.' % path)
+    # PyTorch bundles its own HIP runtime (SONAME libamdhip64.so.7).  It must be in the process
+    # BEFORE our library is opened, so that the library's NEEDED entry binds to that same runtime:
+    # two HIP runtimes in one process cannot share devices, streams or pointers.
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     _CACHE[name] = lib
     return lib

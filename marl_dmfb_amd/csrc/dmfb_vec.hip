@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -122,19 +123,30 @@ __global__ void k_set_map(size_t total, double *health, double *degrade, uint16_
 }
 
 thread_local int g_last_hip = 0;
-#define HIP_TRY(expr)                                   \
-    do {                                                \
-        hipError_t _e = (expr);                         \
-        if (_e != hipSuccess) { g_last_hip = (int)_e; return DMFB_ERR_HIP; } \
+// DMFB_VEC_DEBUG=1 in the environment prints the failing HIP call to stderr.
+inline int hip_fail(hipError_t e, const char *what, int line) {
+    g_last_hip = (int)e;
+    if (getenv("DMFB_VEC_DEBUG")) fprintf(stderr, "dmfb_vec: %s failed at line %d: %s (%d)\n", what, line, hipGetErrorString(e), (int)e);
+    return DMFB_ERR_HIP;
+}
+#define HIP_TRY(expr)                                                 \
+    do {                                                              \
+        hipError_t _e = (expr);                                       \
+        if (_e != hipSuccess) return hip_fail(_e, #expr, __LINE__);   \
     } while (0)
 
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;
     explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
-        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
-        if (prev == dev) prev = -1;
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) { ok = false; hip_fail(e, "hipGetDevice", __LINE__); prev = -1; return; }
+        if (prev != dev) {
+            e = hipSetDevice(dev);
+            if (e != hipSuccess) { ok = false; hip_fail(e, "hipSetDevice", __LINE__); }
+        } else {
+            prev = -1;
+        }
     }
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
@@ -214,6 +226,7 @@ int launch_observe(const dmfb_vec *h, const uint8_t *mask, int8_t *obs, hipStrea
     const int T = h->dc.T;
     const int grid = (h->cfg.n_envs + T - 1) / T;
     const size_t lds = tile_lds_bytes(T, h->cfg.n_agents, h->dc.obs_len);
+    (void)hipGetLastError();  // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(k_observe, dim3(grid), dim3(kBlock), lds, s, h->dc, h->dp, mask, obs);
     HIP_TRY(hipGetLastError());
     return DMFB_OK;
@@ -242,7 +255,7 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
     int rc = dmfb_vec_check_config(cfg);
     if (rc) return rc;
     DeviceGuard g(cfg->device);
-    if (!g.ok) { g_last_hip = (int)hipErrorInvalidDevice; return DMFB_ERR_HIP; }
+    if (!g.ok) return DMFB_ERR_HIP;
     dmfb_vec *h = new (std::nothrow) dmfb_vec();
     if (!h) return DMFB_ERR_BAD_ARG;
     h->cfg = *cfg;
@@ -257,14 +270,19 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
     const size_t st_bytes = (size_t)rec_words(n) * E * 4, starts_bytes = (size_t)((n + 1) / 2) * E * 4;
     hipStream_t s = (hipStream_t)stream;
     auto fail = [&](int code) { dmfb_vec_destroy(h); return code; };
+#define CREATE_TRY(expr)                                                            \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) { hip_fail(_e, #expr, __LINE__); return fail(DMFB_ERR_HIP); } \
+    } while (0)
     memset(&h->dp, 0, sizeof(h->dp));
-    if (hipMalloc(&h->dp.st, st_bytes) != hipSuccess) return fail(DMFB_ERR_HIP);
-    if (hipMalloc(&h->dp.starts, starts_bytes) != hipSuccess) return fail(DMFB_ERR_HIP);
+    CREATE_TRY(hipMalloc(&h->dp.st, st_bytes));
+    CREATE_TRY(hipMalloc(&h->dp.starts, starts_bytes));
     h->bytes = st_bytes + starts_bytes;
     if (cfg->b_degrade || cfg->with_maps) {
-        if (hipMalloc(&h->dp.health, cells * E * 8) != hipSuccess) return fail(DMFB_ERR_HIP);
-        if (hipMalloc(&h->dp.degrade, cells * E * 8) != hipSuccess) return fail(DMFB_ERR_HIP);
-        if (hipMalloc(&h->dp.usage, cells * E * 2) != hipSuccess) return fail(DMFB_ERR_HIP);
+        CREATE_TRY(hipMalloc(&h->dp.health, cells * E * 8));
+        CREATE_TRY(hipMalloc(&h->dp.degrade, cells * E * 8));
+        CREATE_TRY(hipMalloc(&h->dp.usage, cells * E * 2));
         h->bytes += cells * E * 18;
     }
     for (int dd = -255; dd <= 255; ++dd) {
@@ -273,17 +291,16 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
         h->zoom_host[dd + 255] = (int8_t)zx;
         h->zoom_host[511 + dd + 255] = (int8_t)zy;
     }
-    if (hipMalloc(&h->zoom_dev, sizeof(h->zoom_host)) != hipSuccess) return fail(DMFB_ERR_HIP);
+    CREATE_TRY(hipMalloc(&h->zoom_dev, sizeof(h->zoom_host)));
     h->bytes += sizeof(h->zoom_host);
-    if (hipMemcpyAsync(h->zoom_dev, h->zoom_host, sizeof(h->zoom_host), hipMemcpyHostToDevice, s) != hipSuccess)
-        return fail(DMFB_ERR_HIP);
+    CREATE_TRY(hipMemcpyAsync(h->zoom_dev, h->zoom_host, sizeof(h->zoom_host), hipMemcpyHostToDevice, s));
     h->dp.zoom = h->zoom_dev;
-    if (hipMemsetAsync(h->dp.st, 0, st_bytes, s) != hipSuccess) return fail(DMFB_ERR_HIP);
+    CREATE_TRY(hipMemsetAsync(h->dp.st, 0, st_bytes, s));
     d.T = pick_tile(h);
     rc = launch_reset(h, nullptr, 3, s);
     if (rc) return fail(rc);
     // the zoom table upload reads host memory owned by the handle: make it safe to use right away
-    if (hipStreamSynchronize(s) != hipSuccess) return fail(DMFB_ERR_HIP);
+    CREATE_TRY(hipStreamSynchronize(s));
     *out = h;
     return DMFB_OK;
 }
@@ -322,6 +339,7 @@ int dmfb_vec_restart(dmfb_vec *h, const uint8_t *d_mask, int8_t *d_obs, void *st
 int dmfb_vec_set_task(dmfb_vec *h, const int32_t *d_starts, const int32_t *d_ends, void *stream) {
     if (!h || !d_starts || !d_ends) return DMFB_ERR_BAD_ARG;
     DeviceGuard g(h->cfg.device);
+    (void)hipGetLastError();  // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(k_set_task, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dc, h->dp,
                        d_starts, d_ends);
     HIP_TRY(hipGetLastError());
@@ -331,6 +349,7 @@ int dmfb_vec_set_task(dmfb_vec *h, const int32_t *d_starts, const int32_t *d_end
 int dmfb_vec_get_task(const dmfb_vec *h, int32_t *d_starts, int32_t *d_ends, void *stream) {
     if (!h) return DMFB_ERR_BAD_ARG;
     DeviceGuard g(h->cfg.device);
+    (void)hipGetLastError();  // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(k_get_task, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dc, h->dp,
                        d_starts, d_ends);
     HIP_TRY(hipGetLastError());
@@ -356,6 +375,7 @@ int dmfb_vec_get_state(const dmfb_vec *h, int32_t *d_pos, int32_t *d_dist, int32
                        int64_t *d_constraints, void *stream) {
     if (!h) return DMFB_ERR_BAD_ARG;
     DeviceGuard g(h->cfg.device);
+    (void)hipGetLastError();  // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(k_get_state, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dc, h->dp,
                        d_pos, d_dist, d_step_count, d_constraints);
     HIP_TRY(hipGetLastError());
@@ -367,6 +387,7 @@ int dmfb_vec_get_map(const dmfb_vec *h, int which, double *d_buf, void *stream) 
     if (!h->dp.health) return DMFB_ERR_NO_MAPS;
     DeviceGuard g(h->cfg.device);
     const size_t total = (size_t)h->cfg.n_envs * h->cfg.width * h->cfg.length;
+    (void)hipGetLastError();  // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(k_get_map, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
                        h->dp.health, h->dp.degrade, h->dp.usage, which, d_buf);
     HIP_TRY(hipGetLastError());
@@ -378,6 +399,7 @@ int dmfb_vec_set_map(dmfb_vec *h, int which, const double *d_buf, void *stream) 
     if (!h->dp.health) return DMFB_ERR_NO_MAPS;
     DeviceGuard g(h->cfg.device);
     const size_t total = (size_t)h->cfg.n_envs * h->cfg.width * h->cfg.length;
+    (void)hipGetLastError();  // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(k_set_map, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
                        h->dp.health, h->dp.degrade, h->dp.usage, which, d_buf);
     HIP_TRY(hipGetLastError());

@@ -11,6 +11,7 @@ namespace dmfbk {
 template <>
 hipError_t launch_step_n<DMFB_TU_N>(const DevCfg &c, const DevPtrs &p, const StepArgs &a, int grid, size_t lds,
                                     hipStream_t s) {
+    (void)hipGetLastError();  // drop stale errors left by other users of the runtime
     if (p.health) hipLaunchKernelGGL((k_step<DMFB_TU_N, true>), dim3(grid), dim3(kBlock), lds, s, c, p, a);
     else hipLaunchKernelGGL((k_step<DMFB_TU_N, false>), dim3(grid), dim3(kBlock), lds, s, c, p, a);
     return hipGetLastError();
@@ -19,6 +20,7 @@ hipError_t launch_step_n<DMFB_TU_N>(const DevCfg &c, const DevPtrs &p, const Ste
 template <>
 hipError_t launch_reset_n<DMFB_TU_N>(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int mode, int grid,
                                      hipStream_t s) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL((k_reset<DMFB_TU_N>), dim3(grid), dim3(kBlock), 0, s, c, p, mask, mode);
     return hipGetLastError();
 }

@@ -34,7 +34,8 @@ class VecAdapter:
         self.v.set_map(which, np.asarray(arr, np.float64))
 
     def step(self, actions, uniforms=None, record=True, autoreset=False):
-        obs, r, d, info = self.v.step(np.asarray(actions), uniforms, record=record, autoreset=autoreset)
+        a = actions if isinstance(actions, torch.Tensor) else np.asarray(actions)
+        obs, r, d, info = self.v.step(a, uniforms, record=record, autoreset=autoreset)
         torch.cuda.synchronize()
         self.last_obs = obs.cpu().numpy()
         self.last_info = {k: t.cpu().numpy() for k, t in info.items()}
