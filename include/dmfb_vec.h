@@ -109,9 +109,13 @@ int dmfb_vec_get_task(const dmfb_vec *h, int32_t *d_starts, int32_t *d_ends, voi
 
 /* DMFBenv.step(actions, record) (dmfb.py:560-587) for all E envs.
  * d_uniforms: float64[E][n], entry [e][i] is the random.random() draw droplet i of env e
- * takes if it draws (dmfb.py:335), or NULL to use the handle's Philox stream. */
-int dmfb_vec_step(dmfb_vec *h, const void *d_actions, const double *d_uniforms, uint32_t flags,
-                  const dmfb_vec_step_out *out, void *stream);
+ * takes if it draws (dmfb.py:335), or NULL to use the handle's Philox stream.
+ * d_active: uint8[E] or NULL (= all).  Envs whose byte is 0 are NOT stepped (their episode is
+ * over and the caller has not reset them yet, common/rollout.py:46): state untouched, outputs
+ * rewards 0 / dones 1 / constraints 0 / success 0 / team_reward 0 / terminated 1, obs row rewritten
+ * with the unchanged observation. */
+int dmfb_vec_step(dmfb_vec *h, const void *d_actions, const double *d_uniforms, const uint8_t *d_active,
+                  uint32_t flags, const dmfb_vec_step_out *out, void *stream);
 
 /* DMFBenv.getObs() (dmfb.py:622-626): int8[E][n][3*fov*fov+2]; d_mask as in reset. */
 int dmfb_vec_observe(const dmfb_vec *h, const uint8_t *d_mask, int8_t *d_obs, void *stream);

@@ -70,7 +70,7 @@ def dmfb_vec():
     lib.dmfb_vec_restart.argtypes = [vp, vp, vp, vp]
     lib.dmfb_vec_set_task.argtypes = [vp, vp, vp, vp]
     lib.dmfb_vec_get_task.argtypes = [vp, vp, vp, vp]
-    lib.dmfb_vec_step.argtypes = [vp, vp, vp, u32, C.POINTER(DmfbVecStepOut), vp]
+    lib.dmfb_vec_step.argtypes = [vp, vp, vp, vp, u32, C.POINTER(DmfbVecStepOut), vp]
     lib.dmfb_vec_observe.argtypes = [vp, vp, vp, vp]
     lib.dmfb_vec_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.dmfb_vec_get_map.argtypes = [vp, i32, vp, vp]

@@ -1,0 +1,132 @@
+"""Vectorised rollout with the reference's API surface (common/rollout.py:10-150).
+
+The reference plays ONE chip: per step it calls the Q-net once per agent with batch size 1,
+steps the env, and appends the transition; `generate_episode` pads to `episode_limit`.  Here an
+`Evaluator`/`RolloutWorker` owns a `VecDMFB` batch of E chips and plays one episode on EVERY chip
+in lock-step: one Q-net forward over (E x n) rows, epsilon-greedy on the device, one fused HIP
+transition for all chips.  Everything stays in HBM; the episode batch has the reference's keys,
+shapes and padding rules with leading dimension E.
+
+Book-keeping kept from the reference:
+  * team reward = np.sum(rewards)/n (computed inside the transition kernel in numpy's order)
+  * `terminated` = all(dones); an env that terminated is frozen (active mask) until the next reset
+  * padding: zeros, padded = 1, terminated = 1 after the end of an episode (rollout.py:131-141)
+  * `steps` is forced to `episode_limit` for unsuccessful episodes (rollout.py:60-61,148-149)
+  * epsilon anneals per env-step: one lock-step of k live chips anneals k steps (rollout.py:126-127)
+"""
+import torch
+
+
+class Evaluator:
+    def __init__(self, env, agents, episode_limit):
+        self.agents = agents
+        self.env = env
+        self.n_agents = agents.n_agents
+        self.n_actions = agents.n_actions
+        self.episode_limit = episode_limit
+        self.device = env.device
+        self.n_envs = env.n_envs
+        self.generator = None
+        self.sync_every = 4  # lock-steps between host checks for "every chip has terminated"
+        self.reset_fn = None  # tests replace env.reset() (e.g. by restart() on an injected task)
+
+    def _new_round(self, new=False):
+        obs = self.reset_fn() if self.reset_fn is not None else self.env.reset(new=new)
+        E, n = self.n_envs, self.n_agents
+        hidden = torch.zeros((E * n, self.agents.args.rnn_hidden_dim), device=self.device)
+        last_action = torch.zeros((E, n, self.n_actions), dtype=torch.int8, device=self.device)
+        return obs, hidden, last_action
+
+    @torch.no_grad()
+    def _play(self, epsilon, evaluate, record):
+        """One episode on every chip.  Returns per-chip stats and (if record) the episode batch."""
+        E, n, A, T = self.n_envs, self.n_agents, self.n_actions, self.episode_limit
+        dev = self.device
+        obs, hidden, last_action = self._new_round()
+        alive = torch.ones(E, dtype=torch.bool, device=dev)
+        reward = torch.zeros(E, dtype=torch.float64, device=dev)
+        steps = torch.zeros(E, dtype=torch.int64, device=dev)
+        constraints = torch.zeros(E, dtype=torch.int64, device=dev)
+        success = torch.zeros(E, dtype=torch.int64, device=dev)
+        ep = None
+        if record:
+            O = self.env.obs_len
+            ep = {'o': torch.zeros((E, T, n, O), dtype=torch.int8, device=dev),
+                  'u': torch.zeros((E, T, n, 1), dtype=torch.int8, device=dev),
+                  'r': torch.zeros((E, T, 1), dtype=torch.float32, device=dev),
+                  'o_next': torch.zeros((E, T, n, O), dtype=torch.int8, device=dev),
+                  'avail_u': torch.zeros((E, T, n, A), dtype=torch.int8, device=dev),
+                  'avail_u_next': torch.zeros((E, T, n, A), dtype=torch.int8, device=dev),
+                  'u_onehot': torch.zeros((E, T, n, A), dtype=torch.int8, device=dev),
+                  'padded': torch.ones((E, T, 1), dtype=torch.bool, device=dev),
+                  'terminated': torch.ones((E, T, 1), dtype=torch.bool, device=dev)}
+        eps = epsilon
+        for t in range(T):
+            actions, hidden = self.agents.choose_actions(obs, last_action, hidden, eps, evaluate=evaluate,
+                                                         generator=self.generator)
+            onehot = torch.nn.functional.one_hot(actions, A).to(torch.int8)
+            if record:
+                ep['o'][:, t] = torch.where(alive[:, None, None], obs, torch.zeros_like(obs))
+            obs, _, _, info = self.env.step(actions, active=alive, record=True)
+            term = info['terminated'].bool()
+            live = alive
+            if record:
+                m3 = live[:, None, None]
+                ep['u'][:, t] = torch.where(m3, actions.unsqueeze(-1).to(torch.int8), 0)
+                ep['r'][:, t, 0] = torch.where(live, info['team_reward'].float(), 0.0)
+                ep['o_next'][:, t] = torch.where(m3, obs, torch.zeros_like(obs))
+                ep['u_onehot'][:, t] = torch.where(m3, onehot, 0)
+                ep['avail_u'][:, t] = m3.to(torch.int8).expand(E, n, A)
+                ep['avail_u_next'][:, t] = m3.to(torch.int8).expand(E, n, A)
+                ep['padded'][:, t, 0] = ~live
+                ep['terminated'][:, t, 0] = term | ~live
+            reward += torch.where(live, info['team_reward'], 0.0)
+            constraints += torch.where(live, info['constraints'].long(), 0)
+            success += torch.where(live, info['success'].long(), 0)
+            steps += live.long()
+            if not evaluate and self.agents.args.epsilon_anneal_scale == 'step':
+                eps = torch.clamp(eps - self.anneal_epsilon * live.sum(), min=self.min_epsilon)
+            last_action = onehot
+            alive = alive & ~term
+            if (t + 1) % self.sync_every == 0 and not bool(alive.any()):
+                break
+        steps = torch.where(success > 0, steps, torch.full_like(steps, self.episode_limit))
+        return reward, steps, constraints, success, ep, eps
+
+    def _generate_episode(self):
+        """Greedy episode on every chip (rollout.py:41-67): per-chip reward, steps, constraints, success."""
+        self.agents.policy.init_hidden(1)
+        reward, steps, constraints, success, _, _ = self._play(0.0, evaluate=True, record=False)
+        return reward, steps, constraints, success
+
+    def evaluate(self, task_num):
+        """`task_num` consecutive greedy episodes on every chip (the chips keep ageing between
+        episodes, as the single reference chip does); means over all chips and episodes."""
+        tot = [0.0, 0.0, 0.0, 0.0]
+        for _ in range(task_num):
+            out = self._generate_episode()
+            for k in range(4):
+                tot[k] += float(out[k].double().mean().item())
+        return tuple(v / task_num for v in tot)
+
+
+class RolloutWorker(Evaluator):
+    def __init__(self, env, agents, args):
+        super().__init__(env, agents, args.episode_limit)
+        self.n_actions = args.n_actions
+        self.obs_shape = args.obs_shape[-1]
+        self.epsilon_anneal_scale = args.epsilon_anneal_scale
+        self.min_epsilon = args.min_epsilon
+        self.anneal_epsilon = (args.epsilon - args.min_epsilon) / args.anneal_steps
+        self.epsilon = torch.tensor(float(args.epsilon), device=self.device)
+
+    def generate_episode(self):
+        """One episode per chip.  Returns (reward[E], step[E], constraints[E], success[E], episode)
+        where `episode` has the reference's keys with leading dimension E (rollout.py:101-150)."""
+        self.agents.policy.init_hidden(1)
+        epsilon = self.epsilon
+        if self.epsilon_anneal_scale == 'episode':
+            epsilon = torch.clamp(epsilon - self.anneal_epsilon * self.n_envs, min=self.min_epsilon)
+        reward, steps, constraints, success, episode, epsilon = self._play(epsilon, evaluate=False, record=True)
+        self.epsilon = epsilon
+        return reward, steps, constraints, success, episode

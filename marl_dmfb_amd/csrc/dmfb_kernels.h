@@ -328,6 +328,7 @@ template <typename T> __device__ __forceinline__ int load_action(const void *a, 
 struct StepArgs {
     const void *actions;
     const double *uniforms;
+    const uint8_t *active;
     uint32_t flags;
     dmfb_vec_step_out out;
 };
@@ -349,12 +350,24 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
         // ------------------------------------------------------------------ wave 0: one lane per env
         // T <= 64, so lane == env slot in the tile.
         const int lane = tid;
-        const bool active = lane < tv;
-        const int e = tile_base + (active ? lane : 0);
+        const bool present = lane < tv;
+        const int e = tile_base + (present ? lane : 0);
+        const bool active = present && (!a.active || a.active[e]);
         EnvR<N> r;
         bool ended = false;
+        if (present) load_env<N>(p, E, e, r);
+        if (present && !active) {  // episode over, not reset yet: report a finished env, touch nothing
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                if (a.out.d_dones) a.out.d_dones[(size_t)e * N + i] = 1;
+                if (a.out.d_rewards) a.out.d_rewards[(size_t)e * N + i] = 0.0;
+            }
+            if (a.out.d_constraints) a.out.d_constraints[e] = 0;
+            if (a.out.d_success) a.out.d_success[e] = 0;
+            if (a.out.d_terminated) a.out.d_terminated[e] = 1;
+            if (a.out.d_team_reward) a.out.d_team_reward[e] = 0.0;
+        }
         if (active) {
-            load_env<N>(p, E, e, r);
             // ---- moveDroplets (dmfb.py:253-299)
             int code[N], pastx[N], pasty[N], sta[N], dyn[N];
             bool was_done[N];
@@ -502,8 +515,8 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
                 r.rep += 1; r.step = 0; r.cum = 0; r.flags = 0;
             }
         }
-        if (active) {
-            store_env<N>(p, E, e, r, ended);
+        if (active) store_env<N>(p, E, e, r, ended);
+        if (present) {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 t.pos[lane * N + i] = (uint16_t)(r.x[i] | (r.y[i] << 8));

@@ -356,12 +356,13 @@ int dmfb_vec_get_task(const dmfb_vec *h, int32_t *d_starts, int32_t *d_ends, voi
     return DMFB_OK;
 }
 
-int dmfb_vec_step(dmfb_vec *h, const void *d_actions, const double *d_uniforms, uint32_t flags,
-                  const dmfb_vec_step_out *out, void *stream) {
+int dmfb_vec_step(dmfb_vec *h, const void *d_actions, const double *d_uniforms, const uint8_t *d_active,
+                  uint32_t flags, const dmfb_vec_step_out *out, void *stream) {
     if (!h || !d_actions || !out) return DMFB_ERR_BAD_ARG;
+    if (out->d_obs && ((uintptr_t)out->d_obs & 15)) return DMFB_ERR_BAD_ARG;  // 16-byte stores
     DeviceGuard g(h->cfg.device);
     StepArgs a;
-    a.actions = d_actions; a.uniforms = d_uniforms; a.flags = flags; a.out = *out;
+    a.actions = d_actions; a.uniforms = d_uniforms; a.active = d_active; a.flags = flags; a.out = *out;
     return launch_step(h, a, (hipStream_t)stream);
 }
 

@@ -71,6 +71,7 @@ class VecDMFB:
             _check(self.lib.dmfb_vec_create(C.byref(self.cfg), self._stream(), C.byref(self.h)))
         self.obs_len = 3 * fov * fov + 2
         self.max_step = 2 * (width + length)
+        self.timing = None  # set to [] to collect (start, end) HIP event pairs around every step launch
         E, n, dev = n_envs, n_agents, self.device
         # outputs of a transition, allocated once and reused every step
         self.obs = torch.zeros((E, n, self.obs_len), dtype=torch.int8, device=dev)
@@ -144,9 +145,9 @@ class VecDMFB:
         return s, e
 
     # ------------------------------------------------------------------ transition
-    def step(self, actions, uniforms=None, record=True, autoreset=False, out=None):
+    def step(self, actions, uniforms=None, record=True, autoreset=False, active=None, out=None):
         """DMFBenv.step for all envs.  `actions`: int8/int32/int64 tensor [E, n] on the device (or
-        anything array-like).  Returns (obs, rewards, dones, info) as device tensors that are
+        anything array-like); `active` (uint8/bool [E], optional) freezes the envs whose entry is 0.  Returns (obs, rewards, dones, info) as device tensors that are
         REUSED by the next call; info = dict(constraints, success, team_reward, terminated)."""
         if not isinstance(actions, torch.Tensor) or actions.device != self.device:
             actions = self._dev(actions, torch.int32)
@@ -163,7 +164,15 @@ class VecDMFB:
             raise RuntimeError('The number of actions is not the same as n_droplets')  # dmfb.py:272-274
         u = self._dev(uniforms, torch.float64)
         flags = flag | (DMFB_STEP_RECORD if record else 0) | (DMFB_STEP_AUTORESET if autoreset else 0)
-        _check(self.lib.dmfb_vec_step(self.h, _ptr(actions), _ptr(u), flags, C.byref(out or self._out), self._stream()))
+        act = self._mask(active)
+        if self.timing is not None:  # bench.py: HIP events on the launch stream around the kernel
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        _check(self.lib.dmfb_vec_step(self.h, _ptr(actions), _ptr(u), _ptr(act), flags, C.byref(out or self._out),
+                                      self._stream()))
+        if self.timing is not None:
+            ev1.record()
+            self.timing.append((ev0, ev1))
         info = {'constraints': self.constraints, 'success': self.success, 'team_reward': self.team_reward,
                 'terminated': self.terminated}
         return self.obs, self.rewards, self.dones, info

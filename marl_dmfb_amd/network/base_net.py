@@ -1,0 +1,121 @@
+"""Per-agent Q-network of the reference (network/base_net.py:23-71), batched over (envs x agents).
+
+Same modules and `state_dict` keys (conv1, conv2[, conv3], mlp1, rnn, fc1) so reference
+checkpoints load unchanged.  Two additions for the vectorised loop:
+  * `features()` / `recurrent()` split the forward so that VDN.learn can run the non-recurrent
+    part (convs + vector MLP) ONCE over all T time steps instead of T times;
+  * `forward_obs()` takes the int8 observation rows the HIP env writes plus the last-action
+    one-hot, so the rollout never materialises the concatenated float input on the host.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as f
+
+
+# fov -> conv stack, each entry (in_is_image, stride).  Reference network/base_net.py:23-33; for
+# fov 19 the last two entries are the SAME module object (tied weights), reproduced below.
+_CONV_PLAN = {5: [(True, 1)], 7: [(True, 1), (False, 1)], 9: [(True, 1), (False, 1)], 11: [(True, 1), (False, 1)],
+              13: [(True, 1), (False, 1)], 19: [(True, 2), (False, 1), (False, 1)]}
+
+
+def conv_str(fov, id=3, od=32):
+    stack, shared = [], None
+    for from_image, stride in _CONV_PLAN[fov]:
+        if from_image:
+            stack.append(nn.Conv2d(id, od, kernel_size=3, stride=stride))
+        else:
+            if shared is None:
+                shared = nn.Conv2d(od, od, kernel_size=3, stride=stride)
+            stack.append(shared)
+    return stack
+
+
+class CRNN(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        id = args.obs_shape[0]
+        od = args.hyper_hidden_dim
+        self.input_dim = tuple(args.obs_shape)
+        self.rnn_hidden_dim = args.rnn_hidden_dim
+        self.n_actions = args.n_actions
+        self.convs = conv_str(args.fov, id, od)
+        size = args.fov
+        for i, conv in enumerate(self.convs, 1):
+            self.add_module('conv{}'.format(i), conv)
+            size = int((size + 2 * conv.padding[0] - conv.dilation[0] * (conv.kernel_size[0] - 1) - 1) // conv.stride[0] + 1)
+        self.out = size * size * od
+        self.n_pixel = self.input_dim[-1] - self.input_dim[-2]
+        self.mlp1 = nn.Linear(args.obs_shape[-2] + args.n_actions, 10)
+        self.rnn = nn.GRUCell(self.out + 10, args.rnn_hidden_dim)
+        self.fc1 = nn.Linear(args.rnn_hidden_dim, args.n_actions)
+        self.conv_impl = getattr(args, 'conv_impl', 'gemm')  # 'gemm' (GPU default) or 'conv2d'
+
+    # -- non-recurrent part: rows may be (envs*agents) or (episodes*T*agents)
+    def _conv_stack_gemm(self, pixel):
+        """The conv stack as im2col + ONE large GEMM per layer, activations kept channels-last.
+        On the GPU this replaces MIOpen's convolution (whose solver search / kernel compilation for
+        these 9x9 images costs minutes on a fresh box) by plain rocBLAS/hipBLASLt GEMMs with
+        M = rows x output pixels.  Same arithmetic, different summation order."""
+        x = pixel.permute(0, 2, 3, 1)  # (R, H, W, C) view
+        for conv in self.convs:
+            k, s = conv.kernel_size[0], conv.stride[0]
+            win = x.unfold(1, k, s).unfold(2, k, s)          # (R, H', W', C, k, k) view
+            R, Ho, Wo = win.shape[0], win.shape[1], win.shape[2]
+            cols = win.reshape(R * Ho * Wo, -1)              # im2col, K ordered (c, kh, kw) like conv.weight
+            y = torch.addmm(conv.bias, cols, conv.weight.view(conv.out_channels, -1).t())
+            x = f.relu(y).view(R, Ho, Wo, conv.out_channels)
+        return x.permute(0, 3, 1, 2).reshape(x.shape[0], self.out)  # back to the reference's (c, h, w) order
+
+    def features_split(self, pixel, vec):
+        pixel = pixel.reshape((-1,) + self.input_dim[:3])
+        if pixel.is_cuda and self.conv_impl == 'gemm':
+            pixel = self._conv_stack_gemm(pixel)
+        else:
+            for conv in self.convs:
+                pixel = f.relu(conv(pixel))
+            pixel = pixel.reshape((-1, self.out))
+        vec = f.relu(self.mlp1(vec))
+        return torch.cat([pixel, vec], dim=1)
+
+    def features(self, inputs):
+        pixel, vec = torch.split(inputs, [self.n_pixel, self.n_actions + self.input_dim[-2]], dim=1)
+        return self.features_split(pixel, vec)
+
+    def recurrent(self, x, hidden_state):
+        h_in = hidden_state.reshape(-1, self.rnn_hidden_dim)
+        h = self.rnn(x, h_in)
+        return self.fc1(h), h
+
+    def forward(self, inputs, hidden_state):
+        """Reference signature: inputs (R, obs+n_actions) float32, hidden (R, H) -> (q, h)."""
+        return self.recurrent(self.features(inputs), hidden_state)
+
+    def forward_obs(self, obs_i8, last_action_onehot, hidden_state):
+        """obs_i8 (R, 3*fov*fov+2) int8 as written by the env kernels; last_action_onehot (R, n_actions)."""
+        pixel = obs_i8[:, :self.n_pixel].float()
+        vec = torch.cat([obs_i8[:, self.n_pixel:].float(), last_action_onehot.float()], dim=1)
+        return self.recurrent(self.features_split(pixel, vec), hidden_state)
+
+
+class RNN(nn.Module):
+    """network/base_net.py:7-21 (args.net == 'rnn')."""
+
+    def __init__(self, input_shape, args):
+        super().__init__()
+        self.args = args
+        self.fc1 = nn.Linear(input_shape, args.rnn_hidden_dim)
+        self.rnn = nn.GRUCell(args.rnn_hidden_dim, args.rnn_hidden_dim)
+        self.fc2 = nn.Linear(args.rnn_hidden_dim, args.n_actions)
+
+    def features(self, inputs):
+        return f.relu(self.fc1(inputs))
+
+    def recurrent(self, x, hidden_state):
+        h = self.rnn(x, hidden_state.reshape(-1, self.args.rnn_hidden_dim))
+        return self.fc2(h), h
+
+    def forward(self, obs, hidden_state):
+        return self.recurrent(self.features(obs), hidden_state)
+
+    def forward_obs(self, obs_i8, last_action_onehot, hidden_state):
+        return self.forward(torch.cat([obs_i8.float(), last_action_onehot.float()], dim=1), hidden_state)

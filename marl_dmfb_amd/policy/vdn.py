@@ -1,0 +1,225 @@
+"""VDN learner with the reference's API surface (policy/vdn.py:8-218): VDN(args) with
+.learn(batch, max_episode_len, train_step, epsilon=None), .get_q_values, .init_hidden,
+.eval_hidden/.target_hidden, .eval_rnn/.target_rnn, .save_model(train_step=None).
+
+Differences in HOW (not in what is computed):
+  * the batch stays on the device; there is no per-time-step host->device copy
+    (reference: policy/vdn.py:134-165 builds and uploads the inputs every t);
+  * the non-recurrent part of the Q-net (convs + vector MLP) runs once over all T steps, only the
+    GRU cell + head are unrolled over time (reference: whole net T times, vdn.py:174-191);
+  * the target net runs under no_grad (the reference detaches afterwards, vdn.py:117);
+  * data parallel: when torch.distributed is initialised and args.dist is true the gradient of the
+    un-normalised loss and the mask count travel in ONE flat all-reduce over RCCL, then every rank
+    divides, clips and steps identically.
+"""
+import os
+
+import torch
+
+from ..network.base_net import CRNN, RNN
+from ..network.vdn_net import VDNNet
+
+
+def _t(x, device, dtype):
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(x)
+    return x.to(device=device, dtype=dtype)
+
+
+class VDN:
+    def __init__(self, args):
+        self.args = args
+        self.n_actions = args.n_actions
+        self.n_agents = args.n_agents
+        input_shape = args.obs_shape[-1]
+        if args.last_action:
+            input_shape += self.n_actions
+        if args.reuse_network:
+            input_shape += self.n_agents
+        if args.net == 'rnn':
+            self.eval_rnn = RNN(args.obs_shape[-1] + (self.n_actions if args.last_action else 0), args)
+            self.target_rnn = RNN(args.obs_shape[-1] + (self.n_actions if args.last_action else 0), args)
+        elif args.net == 'crnn':
+            self.eval_rnn = CRNN(args)
+            self.target_rnn = CRNN(args)
+        else:
+            raise Exception('No such net')
+        self.eval_vdn_net = VDNNet()
+        self.target_vdn_net = VDNNet()
+        if getattr(args, 'device', None) is not None:
+            self.device = torch.device(args.device)
+        else:
+            self.device = torch.device('cuda', torch.cuda.current_device()) if args.cuda else torch.device('cpu')
+        for m in (self.eval_rnn, self.target_rnn, self.eval_vdn_net, self.target_vdn_net):
+            m.to(self.device)
+
+        self.model_dir = args.model_dir + '/' + args.alg + '/fov{}/'.format(args.fov)
+        if args.load_model:
+            path_rnn = self.model_dir + args.load_model_name + 'rnn_net_params.pkl'
+            path_vdn = self.model_dir + args.load_model_name + 'vdn_net_params.pkl'
+            if os.path.exists(path_rnn):
+                self.eval_rnn.load_state_dict(torch.load(path_rnn, map_location=self.device, weights_only=True))
+                if os.path.exists(path_vdn):
+                    self.eval_vdn_net.load_state_dict(torch.load(path_vdn, map_location=self.device, weights_only=True))
+                print('Successfully load the model: {} and {}'.format(path_rnn, path_vdn))
+            else:
+                raise Exception('No model!')
+
+        self.target_rnn.load_state_dict(self.eval_rnn.state_dict())
+        self.target_vdn_net.load_state_dict(self.eval_vdn_net.state_dict())
+        for p in self.target_rnn.parameters():
+            p.requires_grad_(False)
+
+        self.eval_parameters = list(self.eval_vdn_net.parameters()) + list(self.eval_rnn.parameters())
+        if args.optimizer == 'RMS':
+            self.optimizer = torch.optim.RMSprop(self.eval_parameters, lr=args.lr)
+        elif args.optimizer == 'SGD':
+            self.optimizer = torch.optim.SGD(self.eval_parameters, lr=args.lr)
+        elif args.optimizer == 'ADAM':
+            self.optimizer = torch.optim.Adam(self.eval_parameters, lr=args.lr, betas=(0.9, 0.99))
+        elif args.optimizer == 'ASGD':
+            self.optimizer = torch.optim.Adam(self.eval_parameters, lr=args.lr)
+        else:
+            raise Exception('No such optimizer')
+
+        self.eval_hidden = None
+        self.target_hidden = None
+        self.last_loss = None
+        self.last_grad_norm = None
+        self._flat = None
+        self.dist = bool(getattr(args, 'dist', False)) and torch.distributed.is_available() \
+            and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        if self.dist:
+            self.broadcast_parameters()
+
+    # ------------------------------------------------------------------ data parallel
+    def broadcast_parameters(self, src=0):
+        """Same initial weights on every rank (one flat broadcast)."""
+        params = list(self.eval_rnn.parameters())
+        flat = torch.cat([p.data.reshape(-1) for p in params])
+        torch.distributed.broadcast(flat, src)
+        off = 0
+        for p in params:
+            p.data.copy_(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.target_rnn.load_state_dict(self.eval_rnn.state_dict())
+
+    def _allreduce_grads(self, mask_sum):
+        """ONE collective per learn step: [all gradients of the un-normalised loss, mask count]."""
+        params = [p for p in self.eval_parameters if p.grad is not None]
+        n = sum(p.numel() for p in params)
+        if self._flat is None or self._flat.numel() != n + 1:
+            self._flat = torch.empty(n + 1, dtype=torch.float32, device=self.device)
+        off = 0
+        for p in params:
+            self._flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
+        self._flat[n] = mask_sum
+        torch.distributed.all_reduce(self._flat, op=torch.distributed.ReduceOp.SUM)
+        total = self._flat[n]
+        off = 0
+        for p in params:
+            p.grad.copy_((self._flat[off:off + p.numel()] / total).view_as(p))
+            off += p.numel()
+        return total
+
+    # ------------------------------------------------------------------ learn (policy/vdn.py:79-132)
+    def learn(self, batch, max_episode_len, train_step, epsilon=None):
+        dev, T, n = self.device, max_episode_len, self.n_agents
+        episode_num = batch['o'].shape[0]
+        self.init_hidden(episode_num)
+        u = _t(batch['u'], dev, torch.long)[:, :T]
+        r = _t(batch['r'], dev, torch.float32)[:, :T]
+        avail_u_next = _t(batch['avail_u_next'], dev, torch.float32)[:, :T]
+        terminated = _t(batch['terminated'], dev, torch.float32)[:, :T]
+        mask = 1 - _t(batch['padded'], dev, torch.float32)[:, :T]
+
+        q_evals, q_targets = self.get_q_values(batch, T)
+
+        q_evals = torch.gather(q_evals, dim=3, index=u).squeeze(3)
+        q_targets = q_targets.masked_fill(avail_u_next == 0.0, -9999999)
+        q_targets = q_targets.max(dim=3)[0]
+
+        q_total_eval = self.eval_vdn_net(q_evals)
+        q_total_target = self.target_vdn_net(q_targets)
+        targets = r + self.args.gamma * q_total_target * (1 - terminated)
+        td_error = targets.detach() - q_total_eval
+        masked_td_error = mask * td_error
+
+        self.optimizer.zero_grad()
+        if self.dist:
+            num = (masked_td_error ** 2).sum()
+            num.backward()
+            total = self._allreduce_grads(mask.sum())
+            loss = num.detach() / total
+        else:
+            loss = (masked_td_error ** 2).sum() / mask.sum()
+            loss.backward()
+        self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.eval_parameters, self.args.grad_norm_clip)
+        self.optimizer.step()
+        self.last_loss = loss.detach()
+
+        if train_step > 0 and train_step % self.args.target_update_cycle == 0:
+            self.target_rnn.load_state_dict(self.eval_rnn.state_dict())
+            self.target_vdn_net.load_state_dict(self.eval_vdn_net.state_dict())
+        return self.last_loss
+
+    def _sequence(self, batch, T):
+        """Inputs for t = 0..T (policy/vdn.py:134-165): obs_seq[t] = o[:,0] if t == 0 else
+        o_next[:,t-1]; last-action one-hot is zero at t == 0, else u_onehot[:,t-1].  Returned
+        time-major: obs (T+1, B*n, obs) int8/float, last action (T+1, B*n, A)."""
+        dev = self.device
+        o = _t(batch['o'], dev, batch['o'].dtype if isinstance(batch['o'], torch.Tensor) else torch.float32)
+        o_next = _t(batch['o_next'], dev, o.dtype)
+        B = o.shape[0]
+        obs_seq = torch.cat([o[:, :1], o_next[:, :T]], dim=1)                       # (B, T+1, n, obs)
+        obs_seq = obs_seq.permute(1, 0, 2, 3).reshape(T + 1, B * self.n_agents, -1)
+        la = None
+        if self.args.last_action:
+            uo = _t(batch['u_onehot'], dev, torch.float32)
+            la = torch.cat([torch.zeros_like(uo[:, :1]), uo[:, :T]], dim=1)
+            la = la.permute(1, 0, 2, 3).reshape(T + 1, B * self.n_agents, -1)
+        return obs_seq, la
+
+    def _features(self, net, obs_rows, la_rows):
+        x = obs_rows.float()
+        if la_rows is not None:
+            x = torch.cat([x, la_rows], dim=1)
+        return net.features(x)
+
+    def get_q_values(self, batch, max_episode_len):
+        T, n = max_episode_len, self.n_agents
+        B = batch['o'].shape[0]
+        obs_seq, la = self._sequence(batch, T)
+        R = B * n
+        # eval net sees inputs 0..T-1, target net inputs 1..T, each from a zero hidden state
+        x_eval = self._features(self.eval_rnn, obs_seq[:T].reshape(T * R, -1),
+                                None if la is None else la[:T].reshape(T * R, -1)).view(T, R, -1)
+        with torch.no_grad():
+            x_tgt = self._features(self.target_rnn, obs_seq[1:T + 1].reshape(T * R, -1),
+                                   None if la is None else la[1:T + 1].reshape(T * R, -1)).view(T, R, -1)
+        self.eval_hidden = self.eval_hidden.to(self.device).reshape(R, -1)
+        self.target_hidden = self.target_hidden.to(self.device).reshape(R, -1)
+        q_evals, q_targets = [], []
+        for t in range(T):
+            q_eval, self.eval_hidden = self.eval_rnn.recurrent(x_eval[t], self.eval_hidden)
+            with torch.no_grad():
+                q_target, self.target_hidden = self.target_rnn.recurrent(x_tgt[t], self.target_hidden)
+            q_evals.append(q_eval.view(B, n, -1))
+            q_targets.append(q_target.view(B, n, -1))
+        return torch.stack(q_evals, dim=1), torch.stack(q_targets, dim=1)
+
+    def init_hidden(self, episode_num):
+        shape = (episode_num, self.n_agents, self.args.rnn_hidden_dim)
+        self.eval_hidden = torch.zeros(shape, device=self.device)
+        self.target_hidden = torch.zeros(shape, device=self.device)
+
+    def save_model(self, train_step=None):
+        """File names of the reference (policy/vdn.py:205-218): {i}_[{k}_]rnn_net_params.pkl and the
+        (empty) mixer state dict."""
+        if not os.path.exists(self.model_dir):
+            os.makedirs(self.model_dir)
+        i = self.args.ith_run
+        tag = str(i) + '_' if train_step is None else str(i) + '_' + str(train_step) + '_'
+        torch.save(self.eval_vdn_net.state_dict(), self.model_dir + tag + 'vdn_net_params.pkl')
+        torch.save(self.eval_rnn.state_dict(), self.model_dir + tag + 'rnn_net_params.pkl')

@@ -1,0 +1,43 @@
+"""Shared by the VDN / rollout golden tests: the deterministic weight formula used when the
+goldens were captured from the reference (tools/oracle/gen_vdn_golden.py: det_init)."""
+import numpy as np
+import torch
+
+
+def det_init(module, salt=0.0):
+    with torch.no_grad():
+        for k, (name, p) in enumerate(module.named_parameters()):
+            i = torch.arange(p.numel(), dtype=torch.float64)
+            scale = 0.08 if p.dim() > 1 else 0.02
+            p.copy_((scale * torch.sin(0.37 * i + 1.7 * k + salt)).to(torch.float32).view_as(p))
+
+
+def learn_golden_check(path, device, rtol, atol):
+    from marl_dmfb_amd.agent.agent import Agents
+    from marl_dmfb_amd.common.arguments import make_args
+    g = np.load(path)
+    W, L, n, fov, od, clip = [int(v) for v in g['cfg']]
+    T = 2 * (W + L)
+    args = make_args(drop_num=n, width=W, length=L, fov=fov, cuda=(device != 'cpu'), device=device, n_actions=5,
+                     n_agents=n, obs_shape=(3, fov, fov, 2, 3 * fov * fov + 2), episode_limit=T)
+    assert args.hyper_hidden_dim == od and args.grad_norm_clip == clip
+    agents = Agents(args)
+    det_init(agents.policy.eval_rnn)
+    det_init(agents.policy.target_rnn, salt=0.5)
+    keys = ['o', 'u', 'r', 'o_next', 'avail_u', 'avail_u_next', 'u_onehot', 'padded', 'terminated']
+    names = [str(x) for x in g['names']]
+    assert names == [k for k, _ in agents.policy.eval_rnn.named_parameters()]
+    for step in range(2):
+        batch = {k: torch.as_tensor(g[k]).to(device) for k in keys}
+        batch['padded'] = batch['padded'].bool()
+        batch['terminated'] = batch['terminated'].bool()
+        agents.train(batch, step)
+        np.testing.assert_allclose(float(agents.policy.last_grad_norm), g['grad_norm'][step], rtol=rtol)
+        for name, p in agents.policy.eval_rnn.named_parameters():
+            idx = torch.as_tensor(g['idx/' + name])
+            grad = p.grad.detach().reshape(-1).cpu()[idx].numpy()
+            w = p.detach().reshape(-1).cpu()[idx].numpy()
+            ref_g = g['grad%d/%s' % (step, name)]
+            scale = np.abs(ref_g).max() + 1e-12
+            np.testing.assert_allclose(grad, ref_g, rtol=rtol, atol=atol * scale, err_msg='grad %s step %d' % (name, step))
+            np.testing.assert_allclose(w, g['w%d/%s' % (step, name)], rtol=rtol, atol=2e-6, err_msg='w %s step %d' % (name, step))

@@ -1,0 +1,61 @@
+"""Kernel-level timing of the fused DMFB transition kernel (env-only tier): per-launch time,
+env-steps/s and algorithmic GB/s at several batch sizes.  Development aid; bench.py is the
+contract benchmark."""
+import argparse
+import json
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from marl_dmfb_amd.env.dmfb import VecDMFB  # noqa: E402
+
+CFGS = {
+    'A': dict(width=10, length=10, n_agents=4, fov=9),
+    'D': dict(width=50, length=50, n_agents=10, fov=9),
+    'E': dict(width=20, length=20, n_agents=10, fov=9, b_degrade=True, per_degrade=1.0),
+}
+
+
+def algo_bytes(cfg, ext_uniforms=False):
+    """algorithmic bytes per env-step."""
+    n, fov = cfg['n_agents'], cfg['fov']
+    writes = n * (3 * fov * fov + 2) + 8 * n + n + 5
+    reads = n + (8 * n if ext_uniforms else 0) + (8 * n if cfg.get('b_degrade') else 0)
+    state = 2 * (2 * n + n + 8) + (4 * n if cfg.get('b_degrade') else 0)
+    return writes + reads + state
+
+
+def run(name, E, iters, autoreset=True):
+    cfg = CFGS[name]
+    env = VecDMFB(n_envs=E, seed=0, **cfg)
+    env.reset()
+    g = torch.Generator(device='cuda').manual_seed(0)
+    acts = [torch.randint(0, 5, (E, cfg['n_agents']), device='cuda', generator=g, dtype=torch.int8) for _ in range(8)]
+    for i in range(10):
+        env.step(acts[i % 8], autoreset=autoreset)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for i in range(iters):
+        env.step(acts[i % 8], autoreset=autoreset)
+    t1.record()
+    torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / iters
+    b = algo_bytes(cfg)
+    return dict(cfg=name, E=E, us_per_launch=round(ms * 1e3, 2), env_steps_per_s=round(E / ms * 1e3),
+                algo_GBps=round(E * b / ms / 1e6, 1), frac_of_8TBps=round(E * b / ms / 1e6 / 8000, 4))
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cfg', default='A,D,E')
+    ap.add_argument('--sizes', default='4096,65536,262144,1048576')
+    ap.add_argument('--iters', type=int, default=200)
+    a = ap.parse_args()
+    for name in a.cfg.split(','):
+        for E in [int(s) for s in a.sizes.split(',')]:
+            if name != 'A' and E > 262144:
+                continue
+            print(json.dumps(run(name, E, a.iters)), flush=True)

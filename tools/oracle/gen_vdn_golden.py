@@ -1,0 +1,162 @@
+"""Generate VDN / rollout golden vectors by RUNNING THE REFERENCE (container-only).
+
+  tests/golden/vdn_learn_<tag>.npz   one fixed minibatch, deterministic initial weights ->
+        loss-side quantities of two consecutive `Agents.train` calls of the reference
+        (policy/vdn.py:79-132): clipped gradients, grad norms and weights, sampled.
+  tests/golden/rollout_greedy_4d.npz greedy `RolloutWorker.generate_episode` of the reference
+        (common/rollout.py:101-150) on injected tasks: the full padded episode dict + stats.
+
+Weights are set by `det_init` (a closed formula, shared with the tests) so they do not have to be
+stored.  Run: python tools/oracle/gen_vdn_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+from env.DMFB.dmfb import DMFBenv  # noqa: E402
+from agent.agent import Agents  # noqa: E402
+from common.rollout import RolloutWorker  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 'tests', 'golden')
+QUEUE = ref_shim.DrawQueue()
+
+
+def det_init(module, salt=0.0):
+    """Deterministic weights: w.flat[i] = scale * sin(0.37*i + 1.7*k + salt), k = parameter index."""
+    with torch.no_grad():
+        for k, (name, p) in enumerate(module.named_parameters()):
+            i = torch.arange(p.numel(), dtype=torch.float64)
+            scale = 0.08 if p.dim() > 1 else 0.02
+            p.copy_((scale * torch.sin(0.37 * i + 1.7 * k + salt)).to(torch.float32).view_as(p))
+
+
+def ref_args(drop_num, W, L, fov, env):
+    with open('/root/reference/data-dmfb/TrainParas/{}d.yaml'.format(drop_num)) as f:
+        net, train = yaml.safe_load_all(f.read())
+    a = types.SimpleNamespace(alg='vdn', net='crnn', last_action=True, reuse_network=True, cuda=False, optimizer='ADAM',
+                              gamma=0.99, model_dir='/tmp/model', load_model=False, load_model_name='', ith_run=0,
+                              fov=fov, width=W, length=L, drop_num=drop_num, block_num=0, stall=True)
+    a.__dict__.update(net)
+    a.__dict__.update(train)
+    a.__dict__.update(env.get_env_info())
+    return a
+
+
+def sample_idx(numel, k=512):
+    return np.unique(np.linspace(0, numel - 1, min(k, numel)).astype(np.int64))
+
+
+def gen_learn(tag, drop_num, W, L, fov, B, seed):
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    import random
+    random.seed(seed)
+    env = DMFBenv(W, L, drop_num, 0, fov=fov)
+    args = ref_args(drop_num, W, L, fov, env)
+    agents = Agents(args)
+    det_init(agents.policy.eval_rnn)
+    det_init(agents.policy.target_rnn, salt=0.5)     # different target weights: exercises both nets
+    worker = RolloutWorker(env, agents, args)
+    worker.epsilon = 0.6                             # mixed greedy / random episodes of varied length
+    episodes = [worker.generate_episode()[4] for _ in range(B)]
+    batch = {k: np.concatenate([e[k] for e in episodes], axis=0) for k in episodes[0]}
+    out = {k: (v.astype(np.int8) if k not in ('r',) else v.astype(np.float64)) for k, v in batch.items()}
+    out['padded'] = batch['padded'].astype(np.uint8)
+    out['terminated'] = batch['terminated'].astype(np.uint8)
+    norms = []
+    orig_clip = torch.nn.utils.clip_grad_norm_
+
+    def clip(params, max_norm, *a, **k):
+        n = orig_clip(params, max_norm, *a, **k)
+        norms.append(float(n))
+        return n
+    torch.nn.utils.clip_grad_norm_ = clip
+    names = [n for n, _ in agents.policy.eval_rnn.named_parameters()]
+    for step in range(2):
+        agents.train({k: v.copy() for k, v in batch.items()}, step)
+        for n, p in agents.policy.eval_rnn.named_parameters():
+            idx = sample_idx(p.numel())
+            out['idx/%s' % n] = idx
+            out['grad%d/%s' % (step, n)] = p.grad.detach().reshape(-1)[idx].numpy().copy()
+            out['w%d/%s' % (step, n)] = p.detach().reshape(-1)[idx].numpy().copy()
+    torch.nn.utils.clip_grad_norm_ = orig_clip
+    out['grad_norm'] = np.array(norms)
+    out['names'] = np.array(names)
+    out['cfg'] = np.array([W, L, drop_num, fov, args.hyper_hidden_dim, args.grad_norm_clip])
+    path = os.path.join(OUT, 'vdn_learn_%s.npz' % tag)
+    np.savez_compressed(path, **out)
+    print(os.path.basename(path), 'B=%d grad_norms=%s bytes=%d' % (B, norms, os.path.getsize(path)))
+
+
+def gen_rollout(seed, n_tasks):
+    """Greedy reference rollouts on injected tasks (health 1.0 => no randomness at all)."""
+    W = L = 10
+    n, fov = 4, 9
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    env = DMFBenv(W, L, n, 0, fov=fov)
+    args = ref_args(n, W, L, fov, env)
+    agents = Agents(args)
+    det_init(agents.policy.eval_rnn, salt=0.25)
+    worker = RolloutWorker(env, agents, args)
+    worker.epsilon = 0.0
+    worker.min_epsilon = 0.0
+    worker.anneal_epsilon = 0.0
+    rm = env.routing_manager
+    tasks = {}
+
+    def fake_reset(new=False):       # generate_episode calls env.reset(): replay the injected task instead
+        return env.restart()
+    env.reset = fake_reset
+    # record the smallest gap between the best and second-best Q over all decisions
+    gaps = []
+    orig = agents.policy.eval_rnn.forward
+
+    def fwd(inputs, hidden):
+        q, h = orig(inputs, hidden)
+        s = torch.sort(q.detach().reshape(-1), descending=True).values
+        gaps.append(float(s[0] - s[1]))
+        return q, h
+    agents.policy.eval_rnn.forward = fwd
+    eps, stats, starts, ends = [], [], [], []
+    for k in range(n_tasks):
+        while True:
+            pts = np.stack([rng.integers(0, W, 2 * n), rng.integers(0, L, 2 * n)], axis=1)
+            d = pts[:, None, :] - pts[None, :, :]
+            if ((d ** 2).sum(-1) + np.eye(2 * n, dtype=int) * 99).min() > 2:
+                break
+        if k % 4 == 1:      # every droplet already on its goal: the episode ends after one step (padding path)
+            pts[n:] = pts[:n]
+        elif k % 4 == 2:    # three on their goals, one a single cell away
+            pts[n:] = pts[:n]
+            pts[n, 0] = pts[0, 0] + (1 if pts[0, 0] < W - 1 else -1)
+        rm.starts, rm.ends = pts[:n].copy(), pts[n:].copy()
+        reward, step, cons, succ, ep = worker.generate_episode()
+        eps.append(ep); stats.append([reward, step, cons, succ]); starts.append(pts[:n]); ends.append(pts[n:])
+    out = {k: np.concatenate([e[k] for e in eps], axis=0) for k in eps[0]}
+    for k in ('o', 'o_next', 'u', 'avail_u', 'avail_u_next', 'u_onehot'):
+        out[k] = out[k].astype(np.int8)
+    out['padded'] = out['padded'].astype(np.uint8)
+    out['terminated'] = out['terminated'].astype(np.uint8)
+    out['stats'] = np.array(stats, dtype=np.float64)
+    out['starts'] = np.array(starts, np.int32)
+    out['ends'] = np.array(ends, np.int32)
+    out['min_gap'] = np.array(min(gaps))
+    path = os.path.join(OUT, 'rollout_greedy_4d.npz')
+    np.savez_compressed(path, **out)
+    print(os.path.basename(path), 'episodes=%d min_q_gap=%.3e success=%d bytes=%d' % (
+        n_tasks, min(gaps), int(out['stats'][:, 3].sum()), os.path.getsize(path)))
+
+
+if __name__ == '__main__':
+    gen_learn('4d_od24', 4, 10, 10, 9, B=6, seed=5)
+    gen_learn('10d_od32', 10, 20, 20, 9, B=3, seed=6)
+    gen_rollout(seed=2, n_tasks=16)
