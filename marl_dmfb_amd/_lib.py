@@ -81,3 +81,53 @@ def dmfb_vec():
     lib.dmfb_vec_last_hip_error.argtypes = []
     lib._typed = True
     return lib
+
+
+class MedaVecConfig(C.Structure):
+    """include/meda_vec.h: meda_vec_config"""
+    _fields_ = [('width', C.c_int32), ('length', C.c_int32), ('n_agents', C.c_int32), ('fov', C.c_int32),
+                ('b_degrade', C.c_int32), ('with_maps', C.c_int32), ('per_degrade', C.c_double), ('n_envs', C.c_int32),
+                ('env_id0', C.c_uint32), ('seed', C.c_uint64), ('device', C.c_int32)]
+
+
+class MedaVecStepOut(C.Structure):
+    """include/meda_vec.h: meda_vec_step_out"""
+    _fields_ = [('d_rewards', C.c_void_p), ('d_dones', C.c_void_p), ('d_fail', C.c_void_p), ('d_success', C.c_void_p),
+                ('d_obs', C.c_void_p), ('d_team_reward', C.c_void_p), ('d_terminated', C.c_void_p)]
+
+
+MEDA_VEC_SYMBOLS = [
+    'meda_vec_check_config', 'meda_vec_create', 'meda_vec_destroy', 'meda_vec_state_bytes', 'meda_vec_obs_len',
+    'meda_vec_max_step', 'meda_vec_n_envs', 'meda_vec_n_agents', 'meda_vec_reset', 'meda_vec_restart',
+    'meda_vec_set_task', 'meda_vec_get_task', 'meda_vec_step', 'meda_vec_observe', 'meda_vec_get_state',
+    'meda_vec_get_map', 'meda_vec_set_map', 'meda_vec_strerror', 'meda_vec_last_hip_error',
+]
+
+
+def meda_vec():
+    lib = load('meda_vec')
+    if getattr(lib, '_typed', False):
+        return lib
+    vp, i32, u32 = C.c_void_p, C.c_int, C.c_uint32
+    cfgp = C.POINTER(MedaVecConfig)
+    lib.meda_vec_check_config.argtypes = [cfgp]
+    lib.meda_vec_create.argtypes = [cfgp, vp, C.POINTER(vp)]
+    lib.meda_vec_destroy.argtypes = [vp]
+    lib.meda_vec_state_bytes.argtypes = [vp]
+    lib.meda_vec_state_bytes.restype = C.c_size_t
+    for f in ('meda_vec_obs_len', 'meda_vec_max_step', 'meda_vec_n_envs', 'meda_vec_n_agents'):
+        getattr(lib, f).argtypes = [vp]
+    lib.meda_vec_reset.argtypes = [vp, vp, vp, vp]
+    lib.meda_vec_restart.argtypes = [vp, vp, vp, vp]
+    lib.meda_vec_set_task.argtypes = [vp, vp, vp, vp]
+    lib.meda_vec_get_task.argtypes = [vp, vp, vp, vp]
+    lib.meda_vec_step.argtypes = [vp, vp, vp, vp, u32, C.POINTER(MedaVecStepOut), vp]
+    lib.meda_vec_observe.argtypes = [vp, vp, vp, vp]
+    lib.meda_vec_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.meda_vec_get_map.argtypes = [vp, i32, vp, vp]
+    lib.meda_vec_set_map.argtypes = [vp, i32, vp, vp]
+    lib.meda_vec_strerror.argtypes = [i32]
+    lib.meda_vec_strerror.restype = C.c_char_p
+    lib.meda_vec_last_hip_error.argtypes = []
+    lib._typed = True
+    return lib

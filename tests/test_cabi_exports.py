@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     txt = open(os.path.join(ROOT, 'include', header)).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
-    return sorted(set(re.findall(r'\b(dmfb_vec_[a-z_0-9]+)\s*\(', txt)))
+    prefix = header.split('.')[0]
+    return sorted(set(re.findall(r'\b(%s_[a-z_0-9]+)\s*\(' % prefix, txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -52,3 +53,27 @@ def test_strerror():
     lib = _lib.dmfb_vec()
     assert lib.dmfb_vec_strerror(-2) == b'Fov is too large'
     assert lib.dmfb_vec_strerror(-3) == b'Too many droplets for DMFB'
+
+
+def test_meda_library_exports_every_declared_symbol():
+    lib = _lib.meda_vec()
+    names = _declared('meda_vec.h')
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.MEDA_VEC_SYMBOLS) == names
+
+
+def test_meda_check_config_codes():
+    lib = _lib.meda_vec()
+
+    def cfg(**kw):
+        base = dict(width=30, length=30, n_agents=4, fov=19, b_degrade=0, with_maps=0, per_degrade=0.1, n_envs=8,
+                    env_id0=0, seed=0, device=0)
+        base.update(kw)
+        return _lib.MedaVecConfig(**base)
+    assert lib.meda_vec_check_config(C.byref(cfg())) == 0
+    assert lib.meda_vec_check_config(C.byref(cfg(width=10, length=10))) == -3   # meda.py:151-154
+    assert lib.meda_vec_check_config(C.byref(cfg(n_agents=5))) == -3
+    assert lib.meda_vec_check_config(C.byref(cfg(n_agents=0))) == -5
+    assert lib.meda_vec_check_config(C.byref(cfg(width=0))) == -4
