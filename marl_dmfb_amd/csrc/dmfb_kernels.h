@@ -41,8 +41,11 @@ constexpr uint32_t kTaskMaxRounds = 1u << 16;
 enum : uint32_t { STREAM_MOVE = 1, STREAM_TASK = 2, STREAM_DEGRADE = 3, STREAM_BLOCK = 4 };
 
 struct DevCfg {
-    int W, L, fov, hf, ff, obs_len, max_step, stall, b_degrade, E, n, T;
+    int W, L, fov, hf, ff, obs_len, max_step, stall, b_degrade, E, n;
+    int T;      // chips per workgroup of the launch being made (k_step)
+    int T_obs;  // chips per workgroup of k_observe
     uint32_t k0, k1, env_id0;
+    uint32_t fov_magic;  // ceil(2^32 / fov): k / fov == __umulhi(k, fov_magic) for the ranges used (fov >= 2)
     double per_healthy;
 };
 
@@ -235,21 +238,20 @@ __device__ __forceinline__ void gen_degrade_env(const DevCfg &c, const DevPtrs &
 
 // ---- LDS tile -----------------------------------------------------------------------------------
 struct Tile {
-    int8_t *obs;       // [T][N][obs_len], 16-byte aligned
+    int8_t *obs;       // [T][N][obs_len], 16-byte aligned (absent in the step-only launch)
     uint16_t *pos;     // [T][N]
     uint16_t *goal;    // [T][N]
     uint8_t *flag;     // [T] per-env flag (ended / masked)
 };
-__device__ __forceinline__ size_t tile_obs_bytes(int T, int n, int obs_len) {
-    return ((size_t)T * n * obs_len + 15) & ~(size_t)15;
+__host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+// LDS bytes of a workgroup: obs block (0 for the step-only launch) + pos/goal + flags
+__host__ __device__ inline size_t tile_lds_bytes(int T, int n, int obs_len, bool with_obs) {
+    return (with_obs ? align16((size_t)T * n * obs_len) : 0) + (size_t)T * n * 4 + align16((size_t)T);
 }
-__host__ __device__ inline size_t tile_lds_bytes(int T, int n, int obs_len) {
-    return (((size_t)T * n * obs_len + 15) & ~(size_t)15) + (size_t)T * n * 4 + (((size_t)T + 15) & ~(size_t)15);
-}
-__device__ __forceinline__ Tile carve(unsigned char *smem, int T, int n, int obs_len) {
+__device__ __forceinline__ Tile carve(unsigned char *smem, int T, int n, int obs_len, bool with_obs) {
     Tile t;
     t.obs = (int8_t *)smem;
-    size_t off = tile_obs_bytes(T, n, obs_len);
+    const size_t off = with_obs ? align16((size_t)T * n * obs_len) : 0;
     t.pos = (uint16_t *)(smem + off);
     t.goal = t.pos + (size_t)T * n;
     t.flag = (uint8_t *)(t.goal + (size_t)T * n);
@@ -263,50 +265,51 @@ __device__ __forceinline__ void zero_tile(const Tile &t, int bytes16, int tid, i
 }
 
 // getOneObs (dmfb.py:395-457) for every (env, agent) row of the tile: scatter the non-zero cells.
-// Work items: [0, tv*n) rows for layers 0/1 + direction; [tv*n, tv*n*(1+fov)) boundary-band rows.
+// Pass 1: one lane per row (layers 0/1 + direction).  Pass 2: one lane per (row, window row x) for
+// the out-of-chip bands of layer 2.
+template <int N>
 __device__ __forceinline__ void scatter_tile(const DevCfg &c, const DevPtrs &p, const Tile &t, int tv, int tid,
                                              int nthreads) {
-    const int n = c.n, fov = c.fov, hf = c.hf, ff = c.ff;
-    const int rows = tv * n;
-    for (int it = tid; it < rows * (1 + fov); it += nthreads) {
-        if (it < rows) {
-            const int env = it / n, i = it - env * n;
-            int8_t *row = t.obs + (size_t)it * c.obs_len;
-            const uint16_t *pp = t.pos + env * n, *gp = t.goal + env * n;
-            const int cx = pp[i] & 0xff, cy = pp[i] >> 8;
-            const int ox = cx - hf, oy = cy - hf;
-            for (int j = 0; j < n; ++j) {  // layer 0: all droplets inside the window
-                const int x = (pp[j] & 0xff) - ox, y = (pp[j] >> 8) - oy;
-                if (x >= 0 && x < fov && y >= 0 && y < fov) row[x * fov + y] = (int8_t)(j + 1);
-            }
-            for (int j = 0; j < n; ++j) {  // layer 1: clipped goals of the other visible droplets
-                const int xj = pp[j] & 0xff, yj = pp[j] >> 8;
-                if (j != i && 2 * iabs(xj - cx) < fov && 2 * iabs(yj - cy) < fov) {
-                    int x = (gp[j] & 0xff) - ox, y = (gp[j] >> 8) - oy;
-                    x = x < 0 ? 0 : (x > fov - 1 ? fov - 1 : x);
-                    y = y < 0 ? 0 : (y > fov - 1 ? fov - 1 : y);
-                    row[ff + x * fov + y] = (int8_t)(j + 1);
-                }
-            }
-            row[3 * ff] = p.zoom[(gp[i] & 0xff) - cx + 255];
-            row[3 * ff + 1] = p.zoom[511 + (gp[i] >> 8) - cy + 255];
-        } else {  // layer 2: out-of-chip bands (dmfb.py:428-439), one window row x per item
-            const int k = it - rows;
-            const int r = k / fov, x = k - r * fov;
-            const int env = r / n;
-            const uint16_t pc = t.pos[r];
-            (void)env;
-            const int cx = pc & 0xff, cy = pc >> 8;
-            const int left = hf - cx, right = hf - (c.W - 1 - cx);
-            const int up = hf - cy, down = hf - (c.L - 1 - cy);
-            const bool xb = left > 0 ? (x < left) : (right > 0 ? (x >= fov - right) : false);
-            int y0 = 0, y1 = 0;  // band of y set because of the y bounds
-            if (up > 0) { y0 = 0; y1 = up < fov ? up : fov; }
-            else if (down > 0) { y0 = fov - down < 0 ? 0 : fov - down; y1 = fov; }
-            if (xb) { y0 = 0; y1 = fov; }
-            int8_t *row = t.obs + (size_t)r * c.obs_len + 2 * ff + x * fov;
-            for (int y = y0; y < y1; ++y) row[y] = 1;
+    const int fov = c.fov, hf = c.hf, ff = c.ff;
+    const int rows = tv * N;
+    for (int it = tid; it < rows; it += nthreads) {
+        const int env = it / N, i = it - env * N;
+        int8_t *row = t.obs + (size_t)it * c.obs_len;
+        const uint16_t *pp = t.pos + env * N, *gp = t.goal + env * N;
+        const int cx = pp[i] & 0xff, cy = pp[i] >> 8;
+        const int ox = cx - hf, oy = cy - hf;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {  // layer 0: all droplets inside the window
+            const int x = (pp[j] & 0xff) - ox, y = (pp[j] >> 8) - oy;
+            if (x >= 0 && x < fov && y >= 0 && y < fov) row[x * fov + y] = (int8_t)(j + 1);
         }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {  // layer 1: clipped goals of the other visible droplets, ascending j
+            const int xj = pp[j] & 0xff, yj = pp[j] >> 8;
+            if (j != i && 2 * iabs(xj - cx) < fov && 2 * iabs(yj - cy) < fov) {
+                int x = (gp[j] & 0xff) - ox, y = (gp[j] >> 8) - oy;
+                x = x < 0 ? 0 : (x > fov - 1 ? fov - 1 : x);
+                y = y < 0 ? 0 : (y > fov - 1 ? fov - 1 : y);
+                row[ff + x * fov + y] = (int8_t)(j + 1);
+            }
+        }
+        row[3 * ff] = p.zoom[(gp[i] & 0xff) - cx + 255];
+        row[3 * ff + 1] = p.zoom[511 + (gp[i] >> 8) - cy + 255];
+    }
+    for (int k = tid; k < rows * fov; k += nthreads) {  // layer 2: out-of-chip bands (dmfb.py:428-439)
+        const int r = fov == 1 ? k : (int)__umulhi((uint32_t)k, c.fov_magic);
+        const int x = k - r * fov;
+        const uint16_t pc = t.pos[r];
+        const int cx = pc & 0xff, cy = pc >> 8;
+        const int left = hf - cx, right = hf - (c.W - 1 - cx);
+        const int up = hf - cy, down = hf - (c.L - 1 - cy);
+        const bool xb = left > 0 ? (x < left) : (right > 0 ? (x >= fov - right) : false);
+        int y0 = 0, y1 = 0;  // band of y set because of the y bounds
+        if (up > 0) { y0 = 0; y1 = up < fov ? up : fov; }
+        else if (down > 0) { y0 = fov - down < 0 ? 0 : fov - down; y1 = fov; }
+        if (xb) { y0 = 0; y1 = fov; }
+        int8_t *row = t.obs + (size_t)r * c.obs_len + 2 * ff + x * fov;
+        for (int y = y0; y < y1; ++y) row[y] = 1;
     }
 }
 
@@ -337,21 +340,25 @@ template <int N, bool MAPS>
 __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = c.T, E = c.E;
-    const Tile t = carve(smem, T, N, c.obs_len);
+    const bool want_obs = a.out.d_obs != nullptr;
+    const Tile t = carve(smem, T, N, c.obs_len, want_obs);
     const int tid = threadIdx.x;
     const int tile_base = blockIdx.x * T;
     const int tv = min(T, E - tile_base);
-    const bool want_obs = a.out.d_obs != nullptr;
     const int cells = c.W * c.L;
+    const int wave = tid / kWave, lane = tid % kWave;
+    // Waves whose 64 slots start inside the tile run the transition, one lane per chip (T <= 64 in the
+    // fused launch: wave 0 only; T = 256 in the step-only launch: all four).  The other waves zero the
+    // obs tile meanwhile.
+    const int step_waves = (T + kWave - 1) / kWave;
 
-    if (tid >= kWave) {
-        if (want_obs) zero_tile(t, (int)(tile_obs_bytes(tv, N, c.obs_len) >> 4), tid - kWave, kBlock - kWave);
+    if (wave >= step_waves) {
+        if (want_obs) zero_tile(t, (int)(align16((size_t)tv * N * c.obs_len) >> 4), tid - step_waves * kWave,
+                                kBlock - step_waves * kWave);
     } else {
-        // ------------------------------------------------------------------ wave 0: one lane per env
-        // T <= 64, so lane == env slot in the tile.
-        const int lane = tid;
-        const bool present = lane < tv;
-        const int e = tile_base + (present ? lane : 0);
+        const int slot = tid;
+        const bool present = slot < tv;
+        const int e = tile_base + (present ? slot : 0);
         const bool active = present && (!a.active || a.active[e]);
         EnvR<N> r;
         bool ended = false;
@@ -368,6 +375,39 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
             if (a.out.d_team_reward) a.out.d_team_reward[e] = 0.0;
         }
         if (active) {
+            // ---- everything the serial move loop needs is fetched up front (independent loads in flight
+            // together): actions, and - with maps - the health under every droplet and its draw.  A droplet's
+            // cell before ITS move does not depend on the other droplets' moves.
+            int acts[N];
+            const size_t a0 = (size_t)e * N;
+            if (a.flags & DMFB_ACT_I8) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) acts[i] = ((const int8_t *)a.actions)[a0 + i];
+            } else if (a.flags & DMFB_ACT_I64) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) acts[i] = (int)((const long long *)a.actions)[a0 + i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) acts[i] = ((const int32_t *)a.actions)[a0 + i];
+            }
+            double prob[N], draw[N];
+            const bool use_draws = MAPS || a.uniforms != nullptr;
+            if (use_draws) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    prob[i] = 1.0;
+                    if (MAPS) prob[i] = p.health[(size_t)e * cells + r.x[i] * c.L + r.y[i]];  // getMoveProb (dmfb.py:361-363)
+                    if (a.uniforms) draw[i] = a.uniforms[a0 + i];
+                }
+                if (!a.uniforms) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        uint32_t w[4];
+                        philox(c.k0, c.k1, c.env_id0 + (uint32_t)e, r.rstep, (uint32_t)i, STREAM_MOVE << 8, w);
+                        draw[i] = u53(w[0], w[1]);
+                    }
+                }
+            }
             // ---- moveDroplets (dmfb.py:253-299)
             int code[N], pastx[N], pasty[N], sta[N], dyn[N];
             bool was_done[N];
@@ -380,27 +420,11 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
                 const int x0 = r.x[i], y0 = r.y[i];
                 const int old = iabs(x0 - r.gx[i]) + iabs(y0 - r.gy[i]);
                 pastx[i] = x0; pasty[i] = y0;
-                int act;
-                const size_t ai = (size_t)e * N + i;
-                if (a.flags & DMFB_ACT_I8) act = load_action<int8_t>(a.actions, ai);
-                else if (a.flags & DMFB_ACT_I64) act = load_action<long long>(a.actions, ai);
-                else act = load_action<int32_t>(a.actions, ai);
+                const int act = acts[i];
                 if (c.stall && old == 0) {
                     code[i] = 0;
                 } else {
-                    bool mv = true;
-                    if (MAPS || a.uniforms) {
-                        double u;
-                        if (a.uniforms) u = a.uniforms[ai];
-                        else {
-                            uint32_t w[4];
-                            philox(c.k0, c.k1, c.env_id0 + (uint32_t)e, r.rstep, (uint32_t)i, STREAM_MOVE << 8, w);
-                            u = u53(w[0], w[1]);
-                        }
-                        double prob = 1.0;
-                        if (MAPS) prob = p.health[(size_t)e * cells + x0 * c.L + y0];  // getMoveProb (dmfb.py:361-363)
-                        mv = (u <= prob);
-                    }
+                    const bool mv = use_draws ? (draw[i] <= prob[i]) : true;
                     if (mv) {
                         int nx = x0 + (act == 1) - (act == 2), ny = y0 + (act == 4) - (act == 3);  // Droplet.move (dmfb.py:103-124)
                         nx = nx > c.W - 1 ? c.W - 1 : (nx < 0 ? 0 : nx);
@@ -504,7 +528,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
         while (m) {
             const int src = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const uint32_t gid = c.env_id0 + (uint32_t)(tile_base + src);
+            const uint32_t gid = c.env_id0 + (uint32_t)(tile_base + wave * kWave + src);
             const uint32_t ep = (uint32_t)__shfl((int)r.rep, src, kWave);
             uint32_t pts[N];
             gen_task_wave<N>(c, gid, ep, pts);
@@ -517,23 +541,70 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
         }
         if (active) store_env<N>(p, E, e, r, ended);
         if (present) {
+            if (want_obs) {
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                t.pos[lane * N + i] = (uint16_t)(r.x[i] | (r.y[i] << 8));
-                t.goal[lane * N + i] = (uint16_t)(r.gx[i] | (r.gy[i] << 8));
+                for (int i = 0; i < N; ++i) {
+                    t.pos[slot * N + i] = (uint16_t)(r.x[i] | (r.y[i] << 8));
+                    t.goal[slot * N + i] = (uint16_t)(r.gx[i] | (r.gy[i] << 8));
+                }
             }
-            t.flag[lane] = (uint8_t)ended;
+            t.flag[slot] = (uint8_t)ended;
         }
     }
+    if (!want_obs && !(MAPS && (a.flags & DMFB_STEP_AUTORESET))) return;
     __syncthreads();
     if (MAPS && (a.flags & DMFB_STEP_AUTORESET)) {  // updateHealth for the envs that were reset (dmfb.py:182-183)
         for (int s = 0; s < tv; ++s)
             if (t.flag[s]) update_health_env(p, cells, tile_base + s, tid, kBlock);
     }
     if (!want_obs) return;
-    scatter_tile(c, p, t, tv, tid, kBlock);
+    scatter_tile<N>(c, p, t, tv, tid, kBlock);
     __syncthreads();
     copy_tile_out(t, a.out.d_obs, (size_t)tile_base * N * c.obs_len, tv * N * c.obs_len, tid, kBlock);
+}
+
+// ---- standalone observation kernel (getObs after reset/restart/set_task, and the second launch of the
+// step-only + observe pair used for large batches) ---------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_observe(DevCfg c, DevPtrs p, const uint8_t *mask, int8_t *gobs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int T = c.T_obs, E = c.E;
+    const Tile t = carve(smem, T, N, c.obs_len, true);
+    const int tid = threadIdx.x;
+    const int tile_base = blockIdx.x * T;
+    const int tv = min(T, E - tile_base);
+    constexpr int NP = Rec<N>::NP;
+    bool all = true, any = true;
+    if (mask) {
+        int cnt = 0;
+        for (int s = 0; s < tv; ++s) cnt += mask[tile_base + s] != 0;
+        all = cnt == tv; any = cnt > 0;
+    }
+    if (!any) return;
+    for (int it = tid; it < tv * NP; it += kBlock) {  // coalesced: consecutive lanes, consecutive chips
+        const int w = it / tv, s = it - w * tv;
+        const int e = tile_base + s;
+        const uint32_t pw = p.st[(size_t)w * E + e], gw = p.st[(size_t)(NP + w) * E + e];
+        t.pos[s * N + 2 * w] = (uint16_t)pw;
+        t.goal[s * N + 2 * w] = (uint16_t)gw;
+        if (2 * w + 1 < N) {
+            t.pos[s * N + 2 * w + 1] = (uint16_t)(pw >> 16);
+            t.goal[s * N + 2 * w + 1] = (uint16_t)(gw >> 16);
+        }
+    }
+    zero_tile(t, (int)(align16((size_t)tv * N * c.obs_len) >> 4), tid, kBlock);
+    __syncthreads();
+    scatter_tile<N>(c, p, t, tv, tid, kBlock);
+    __syncthreads();
+    const int row_bytes = N * c.obs_len;
+    if (all) {
+        copy_tile_out(t, gobs, (size_t)tile_base * row_bytes, tv * row_bytes, tid, kBlock);
+    } else {
+        for (int s = 0; s < tv; ++s)
+            if (mask[tile_base + s])
+                for (int b = tid; b < row_bytes; b += kBlock)
+                    gobs[(size_t)(tile_base + s) * row_bytes + b] = t.obs[(size_t)s * row_bytes + b];
+    }
 }
 
 // ---- reset / restart / init: one wave per env -------------------------------------------------------
@@ -598,5 +669,8 @@ template <int N>
 hipError_t launch_step_n(const DevCfg &c, const DevPtrs &p, const StepArgs &a, int grid, size_t lds, hipStream_t s);
 template <int N>
 hipError_t launch_reset_n(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int mode, int grid, hipStream_t s);
+template <int N>
+hipError_t launch_observe_n(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int8_t *obs, int grid, size_t lds,
+                            hipStream_t s);
 
 }  // namespace dmfbk

@@ -16,44 +16,6 @@ using namespace dmfbk;
 
 namespace {
 
-// ---- standalone observation kernel (getObs after reset/restart/set_task) ---------------------------
-__global__ __launch_bounds__(kBlock) void k_observe(DevCfg c, DevPtrs p, const uint8_t *mask, int8_t *gobs) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int T = c.T, E = c.E, n = c.n;
-    const Tile t = carve(smem, T, n, c.obs_len);
-    const int tid = threadIdx.x;
-    const int tile_base = blockIdx.x * T;
-    const int tv = min(T, E - tile_base);
-    const int np = (n + 1) / 2;
-    bool all = true, any = true;
-    if (mask) {
-        int cnt = 0;
-        for (int s = 0; s < tv; ++s) cnt += mask[tile_base + s] != 0;
-        all = cnt == tv; any = cnt > 0;
-    }
-    if (!any) return;
-    for (int it = tid; it < tv * n; it += kBlock) {
-        const int s = it / n, i = it - s * n;
-        const int e = tile_base + s;
-        const uint32_t pw = p.st[(size_t)(i >> 1) * E + e], gw = p.st[(size_t)(np + (i >> 1)) * E + e];
-        t.pos[it] = (uint16_t)(pw >> (16 * (i & 1)));
-        t.goal[it] = (uint16_t)(gw >> (16 * (i & 1)));
-    }
-    zero_tile(t, (int)(tile_obs_bytes(tv, n, c.obs_len) >> 4), tid, kBlock);
-    __syncthreads();
-    scatter_tile(c, p, t, tv, tid, kBlock);
-    __syncthreads();
-    const int row_bytes = n * c.obs_len;
-    if (all) {
-        copy_tile_out(t, gobs, (size_t)tile_base * row_bytes, tv * row_bytes, tid, kBlock);
-    } else {
-        for (int s = 0; s < tv; ++s)
-            if (mask[tile_base + s])
-                for (int b = tid; b < row_bytes; b += kBlock)
-                    gobs[(size_t)(tile_base + s) * row_bytes + b] = t.obs[(size_t)s * row_bytes + b];
-    }
-}
-
 // ---- small utility kernels -----------------------------------------------------------------------
 __global__ void k_set_task(DevCfg c, DevPtrs p, const int32_t *starts, const int32_t *ends) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,25 +132,49 @@ struct dmfb_vec {
     int8_t zoom_host[2 * 511];
     int8_t *zoom_dev = nullptr;
     size_t bytes = 0;
-    int T_step = 16;
+    int T_fused = 16;    // chips per workgroup of the fused step+observe launch (<= 64)
+    int T_obs = 16;      // chips per workgroup of k_observe
+    int split_min = 0;   // batches of at least this many chips use the step-only + observe pair
 };
 
 namespace {
 
-int pick_tile(const dmfb_vec *h) {
-    // T is a multiple of 16 (keeps every tile's obs offset 16-byte aligned), at most 64 (wave 0 owns
-    // one env per lane), small enough that >= 4 workgroups fit a CU's 160 KiB LDS, and small enough
-    // that the grid still covers the 256 CUs when the batch is small.
+// Tile of the LDS-staged observation: a multiple of 16 chips (keeps every tile's obs offset
+// 16-byte aligned), at most 64, obs block <= 40 KB so that >= 3-4 workgroups share a CU's 160 KiB,
+// and shrunk while the grid would not cover the 256 CUs a few times over.
+int pick_tile(const dmfb_vec *h, int min_groups) {
     const int row = h->cfg.n_agents * h->dc.obs_len;
     int T = 64;
     while (T > 16 && (size_t)T * row > 40 * 1024) T -= 16;
-    while (T > 16 && (h->cfg.n_envs + T - 1) / T < 1024) T -= 16;
+    while (T > 16 && (h->cfg.n_envs + T - 1) / T < min_groups) T -= 16;
     return T;
 }
 
+constexpr int kStepOnlyTile = 256;  // step-only launch: every wave of the workgroup owns 64 chips
+
+template <int N> int observe_n(const dmfb_vec *h, const uint8_t *mask, int8_t *obs, hipStream_t s) {
+    const int T = h->T_obs;
+    HIP_TRY(launch_observe_n<N>(h->dc, h->dp, mask, obs, (h->cfg.n_envs + T - 1) / T,
+                                tile_lds_bytes(T, N, h->dc.obs_len, true), s));
+    return DMFB_OK;
+}
+
+// One fused launch for small batches (launch latency dominates); for large batches a step-only launch
+// (all four waves stepping, no LDS tile, high occupancy) followed by the observation kernel.
 template <int N> int step_n(dmfb_vec *h, const StepArgs &a, hipStream_t s) {
-    const int T = h->dc.T;
-    HIP_TRY(launch_step_n<N>(h->dc, h->dp, a, (h->cfg.n_envs + T - 1) / T, tile_lds_bytes(T, N, h->dc.obs_len), s));
+    const int E = h->cfg.n_envs;
+    if (a.out.d_obs && E >= h->split_min) {
+        StepArgs b = a;
+        b.out.d_obs = nullptr;
+        DevCfg c = h->dc;
+        c.T = kStepOnlyTile;
+        HIP_TRY(launch_step_n<N>(c, h->dp, b, (E + c.T - 1) / c.T, tile_lds_bytes(c.T, N, c.obs_len, false), s));
+        return observe_n<N>(h, nullptr, a.out.d_obs, s);
+    }
+    DevCfg c = h->dc;
+    const bool with_obs = a.out.d_obs != nullptr;
+    c.T = with_obs ? h->T_fused : kStepOnlyTile;
+    HIP_TRY(launch_step_n<N>(c, h->dp, a, (E + c.T - 1) / c.T, tile_lds_bytes(c.T, N, c.obs_len, with_obs), s));
     return DMFB_OK;
 }
 template <int N> int reset_n(dmfb_vec *h, const uint8_t *mask, int mode, hipStream_t s) {
@@ -218,18 +204,11 @@ template <int N> int reset_n(dmfb_vec *h, const uint8_t *mask, int mode, hipStre
     }
 
 int launch_step(dmfb_vec *h, const StepArgs &a, hipStream_t s) { DISPATCH_N(h->cfg.n_agents, step_n, h, a, s) }
+int launch_observe(const dmfb_vec *h, const uint8_t *mask, int8_t *obs, hipStream_t s) {
+    DISPATCH_N(h->cfg.n_agents, observe_n, h, mask, obs, s)
+}
 int launch_reset(dmfb_vec *h, const uint8_t *mask, int mode, hipStream_t s) {
     DISPATCH_N(h->cfg.n_agents, reset_n, h, mask, mode, s)
-}
-
-int launch_observe(const dmfb_vec *h, const uint8_t *mask, int8_t *obs, hipStream_t s) {
-    const int T = h->dc.T;
-    const int grid = (h->cfg.n_envs + T - 1) / T;
-    const size_t lds = tile_lds_bytes(T, h->cfg.n_agents, h->dc.obs_len);
-    (void)hipGetLastError();  // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL(k_observe, dim3(grid), dim3(kBlock), lds, s, h->dc, h->dp, mask, obs);
-    HIP_TRY(hipGetLastError());
-    return DMFB_OK;
 }
 
 }  // namespace
@@ -246,7 +225,7 @@ int dmfb_vec_check_config(const dmfb_vec_config *c) {
         c->n_blocks != 0)
         return DMFB_ERR_UNSUPPORTED;
     if (c->n_envs <= 0) return DMFB_ERR_BAD_ARG;
-    if (tile_lds_bytes(16, c->n_agents, 3 * c->fov * c->fov + 2) > 64 * 1024) return DMFB_ERR_UNSUPPORTED;
+    if (tile_lds_bytes(16, c->n_agents, 3 * c->fov * c->fov + 2, true) > 64 * 1024) return DMFB_ERR_UNSUPPORTED;
     return DMFB_OK;
 }
 
@@ -296,7 +275,14 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
     CREATE_TRY(hipMemcpyAsync(h->zoom_dev, h->zoom_host, sizeof(h->zoom_host), hipMemcpyHostToDevice, s));
     h->dp.zoom = h->zoom_dev;
     CREATE_TRY(hipMemsetAsync(h->dp.st, 0, st_bytes, s));
-    d.T = pick_tile(h);
+    d.fov_magic = d.fov >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)d.fov - 1) / (uint64_t)d.fov) : 0u;
+    h->T_fused = pick_tile(h, 1024);
+    h->T_obs = pick_tile(h, 2048);
+    d.T = h->T_fused; d.T_obs = h->T_obs;
+    for (uint32_t k = 0; k < 64u * DMFB_MAX_AGENTS * (uint32_t)d.fov && d.fov >= 2; ++k)  // the magic must be exact on the range used
+        if ((uint32_t)(((uint64_t)k * d.fov_magic) >> 32) != k / (uint32_t)d.fov) return fail(DMFB_ERR_UNSUPPORTED);
+    h->split_min = 32768;
+    if (const char *v = getenv("DMFB_VEC_SPLIT_MIN_ENVS")) h->split_min = atoi(v);  // tuning / test knob
     rc = launch_reset(h, nullptr, 3, s);
     if (rc) return fail(rc);
     // the zoom table upload reads host memory owned by the handle: make it safe to use right away

@@ -154,3 +154,14 @@ def test_full_size_invariants(cfg, E):
         assert bool((moved[was_done] == 0).all())                   # finished droplets stay (stall, dmfb.py:331)
         assert bool((o[:, :, 2 * ff:3 * ff] <= 1).all() and (o[:, :, :2 * ff] <= n).all() and (o >= -10).all())
         prev = st
+
+
+def test_lockstep_split_launch_path(monkeypatch):
+    """Large batches use a step-only launch (all four waves stepping) + the observation kernel;
+    DMFB_VEC_SPLIT_MIN_ENVS=1 forces that path at test sizes.  Must be bit-identical too."""
+    monkeypatch.setenv('DMFB_VEC_SPLIT_MIN_ENVS', '1')
+    assert _lockstep(A, E=1500, steps=100, seed=51, autoreset=True) > 1000
+    _lockstep(A, E=300, steps=60, seed=52, autoreset=False)
+    _lockstep(D, E=300, steps=230, seed=53, autoreset=True, greedy=0.9)
+    _lockstep(Ecfg, E=333, steps=150, seed=54, autoreset=True, greedy=0.8)
+    _lockstep(dict(width=12, length=9, n_agents=3, fov=7, with_maps=True), E=100, steps=60, seed=55, autoreset=True)
