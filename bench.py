@@ -49,6 +49,7 @@ def parse():
     ap.add_argument('--batch_size', type=int, default=512, help='episodes per learn')
     ap.add_argument('--train_time', type=int, default=4, help='learns per round')
     ap.add_argument('--buffer_size', type=int, default=16384, help='episodes kept in the HBM replay buffer')
+    ap.add_argument('--no_graph', action='store_true', help='run the rollout eagerly instead of replaying a HIP graph')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_tiers', action='store_true')
     ap.add_argument('--roofline_envs', type=int, default=262144, help='batch for the large-batch roofline figure')
@@ -176,6 +177,7 @@ def main():
     env = VecDMFB(n_envs=a.n_envs, seed=1234, env_id0=rank * a.n_envs, device=device, **cfg)
     args = make_args(drop_num=a.drop_num, width=a.width, length=a.length, fov=a.fov, device=str(device), dist=dist,
                      n_envs=a.n_envs, batch_size=a.batch_size, train_time=a.train_time, buffer_size=a.buffer_size,
+                     use_graph=not a.no_graph,
                      **env.get_env_info())
     torch.manual_seed(1234 + rank)
     trainer = Trainer(env, args)

@@ -29,6 +29,11 @@ class Evaluator:
         self.generator = None
         self.sync_every = 4  # lock-steps between host checks for "every chip has terminated"
         self.reset_fn = None  # tests replace env.reset() (e.g. by restart() on an injected task)
+        # HIP-graph mode: the whole lock-step episode (reset, T x [Q-net, epsilon-greedy, fused env
+        # transition, book-keeping]) is captured once and replayed, which removes the per-op host
+        # launch cost that otherwise dominates a lock-step of a few thousand chips.
+        self.use_graph = False
+        self._graphs = {}
 
     def _new_round(self, new=False):
         obs = self.reset_fn() if self.reset_fn is not None else self.env.reset(new=new)
@@ -36,6 +41,36 @@ class Evaluator:
         hidden = torch.zeros((E * n, self.agents.args.rnn_hidden_dim), device=self.device)
         last_action = torch.zeros((E, n, self.n_actions), dtype=torch.int8, device=self.device)
         return obs, hidden, last_action
+
+    _capturing = False
+
+    @torch.no_grad()
+    def _play_graphed(self, epsilon, evaluate, record):
+        """_play through a captured HIP graph (one graph per (evaluate, record) mode).  epsilon lives in
+        a static device tensor that the graph reads and (when annealing) updates in place."""
+        key = (bool(evaluate), bool(record))
+        g = self._graphs.get(key)
+        if g is None:
+            eps_in = torch.zeros((), device=self.device)
+            eps_in.copy_(torch.as_tensor(epsilon, device=self.device, dtype=torch.float32))
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):  # warm-up outside capture (lazy inits, rocBLAS handles)
+                self._play(eps_in.clone(), evaluate, record)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            self._capturing = True
+            try:
+                with torch.cuda.graph(graph):
+                    out = self._play(eps_in, evaluate, record)
+            finally:
+                self._capturing = False
+            g = {'graph': graph, 'eps_in': eps_in, 'out': out}
+            self._graphs[key] = g
+        g['eps_in'].copy_(torch.as_tensor(epsilon, device=self.device, dtype=torch.float32))
+        g['graph'].replay()
+        return g['out']
 
     @torch.no_grad()
     def _play(self, epsilon, evaluate, record):
@@ -88,7 +123,7 @@ class Evaluator:
                 eps = torch.clamp(eps - self.anneal_epsilon * live.sum(), min=self.min_epsilon)
             last_action = onehot
             alive = alive & ~term
-            if (t + 1) % self.sync_every == 0 and not bool(alive.any()):
+            if not self._capturing and (t + 1) % self.sync_every == 0 and not bool(alive.any()):
                 break
         steps = torch.where(success > 0, steps, torch.full_like(steps, self.episode_limit))
         return reward, steps, constraints, success, ep, eps
@@ -96,7 +131,8 @@ class Evaluator:
     def _generate_episode(self):
         """Greedy episode on every chip (rollout.py:41-67): per-chip reward, steps, constraints, success."""
         self.agents.policy.init_hidden(1)
-        reward, steps, constraints, success, _, _ = self._play(0.0, evaluate=True, record=False)
+        play = self._play_graphed if self.use_graph else self._play
+        reward, steps, constraints, success, _, _ = play(0.0, evaluate=True, record=False)
         return reward, steps, constraints, success
 
     def evaluate(self, task_num):
@@ -127,6 +163,7 @@ class RolloutWorker(Evaluator):
         epsilon = self.epsilon
         if self.epsilon_anneal_scale == 'episode':
             epsilon = torch.clamp(epsilon - self.anneal_epsilon * self.n_envs, min=self.min_epsilon)
-        reward, steps, constraints, success, episode, epsilon = self._play(epsilon, evaluate=False, record=True)
-        self.epsilon = epsilon
+        play = self._play_graphed if self.use_graph else self._play
+        reward, steps, constraints, success, episode, epsilon = play(epsilon, evaluate=False, record=True)
+        self.epsilon = epsilon.clone() if self.use_graph else epsilon
         return reward, steps, constraints, success, episode

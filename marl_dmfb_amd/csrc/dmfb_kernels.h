@@ -480,10 +480,19 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
                 rew[i] = v;
             }
             if (MAPS && (a.flags & DMFB_STEP_RECORD)) {  // addUsage (dmfb.py:459-463)
+                uint16_t *um = p.usage + (size_t)e * cells;
+                if (!dup) {  // droplets sit on distinct cells: all loads in flight together, then all stores
+                    uint16_t uv[N];
 #pragma unroll
-                for (int i = 0; i < N; ++i)
-                    if ((iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) != 0)
-                        p.usage[(size_t)e * cells + r.x[i] * c.L + r.y[i]] += 1;
+                    for (int i = 0; i < N; ++i) uv[i] = um[r.x[i] * c.L + r.y[i]];
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        if ((iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) != 0) um[r.x[i] * c.L + r.y[i]] = (uint16_t)(uv[i] + 1);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        if ((iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) != 0) um[r.x[i] * c.L + r.y[i]] += 1;
+                }
             }
             r.cum += (uint32_t)constraints;
             const bool in_time = (int)r.step < c.max_step;  // DMFBenv.step (dmfb.py:577-585)
@@ -554,8 +563,16 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
     if (!want_obs && !(MAPS && (a.flags & DMFB_STEP_AUTORESET))) return;
     __syncthreads();
     if (MAPS && (a.flags & DMFB_STEP_AUTORESET)) {  // updateHealth for the envs that were reset (dmfb.py:182-183)
-        for (int s = 0; s < tv; ++s)
-            if (t.flag[s]) update_health_env(p, cells, tile_base + s, tid, kBlock);
+        // one flag read per thread + a wave ballot instead of a serial scan of the tile's flags
+        for (int base = 0; base < tv; base += kBlock) {
+            const int s = base + tid;
+            unsigned long long fm = __ballot(s < tv && t.flag[s] != 0);
+            while (fm) {
+                const int src = __ffsll((long long)fm) - 1;
+                fm &= fm - 1;
+                update_health_env(p, cells, tile_base + base + wave * kWave + src, lane, kWave);
+            }
+        }
     }
     if (!want_obs) return;
     scatter_tile<N>(c, p, t, tv, tid, kBlock);

@@ -18,6 +18,32 @@ _CONV_PLAN = {5: [(True, 1)], 7: [(True, 1), (False, 1)], 9: [(True, 1), (False,
               13: [(True, 1), (False, 1)], 19: [(True, 2), (False, 1), (False, 1)]}
 
 
+class _ConvGemm(torch.autograd.Function):
+    """y = cols @ W^T + b for an im2col matrix with millions of rows and a few dozen columns.
+    Only the backward differs from addmm: the weight gradient reduces over the huge M dimension, which
+    a single skinny GEMM does on a handful of workgroups; here it is split into S independent chunks
+    (batched GEMM) that are summed afterwards, and no gradient is formed for `cols` when it does not
+    need one (first layer: the observation)."""
+
+    @staticmethod
+    def forward(ctx, cols, weight2d, bias):
+        ctx.save_for_backward(cols, weight2d)
+        return torch.addmm(bias, cols, weight2d.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        cols, w = ctx.saved_tensors
+        g = g.contiguous()
+        gcols = g @ w if ctx.needs_input_grad[0] else None
+        M, K = cols.shape
+        C = g.shape[1]
+        S = 1
+        while S < 512 and M % (S * 2) == 0 and M // (S * 2) >= 1024:
+            S *= 2
+        gw = torch.bmm(g.view(S, M // S, C).transpose(1, 2), cols.view(S, M // S, K)).sum(0)
+        return gcols, gw, g.sum(0)
+
+
 def conv_str(fov, id=3, od=32):
     stack, shared = [], None
     for from_image, stride in _CONV_PLAN[fov]:
@@ -62,7 +88,7 @@ class CRNN(nn.Module):
             win = x.unfold(1, k, s).unfold(2, k, s)          # (R, H', W', C, k, k) view
             R, Ho, Wo = win.shape[0], win.shape[1], win.shape[2]
             cols = win.reshape(R * Ho * Wo, -1)              # im2col, K ordered (c, kh, kw) like conv.weight
-            y = torch.addmm(conv.bias, cols, conv.weight.view(conv.out_channels, -1).t())
+            y = _ConvGemm.apply(cols, conv.weight.view(conv.out_channels, -1), conv.bias)
             x = f.relu(y).view(R, Ho, Wo, conv.out_channels)
         return x.permute(0, 3, 1, 2).reshape(x.shape[0], self.out)  # back to the reference's (c, h, w) order
 
@@ -85,6 +111,28 @@ class CRNN(nn.Module):
         h_in = hidden_state.reshape(-1, self.rnn_hidden_dim)
         h = self.rnn(x, h_in)
         return self.fc1(h), h
+
+    def recurrent_seq(self, x_seq, h0):
+        """GRU cell + head over a whole sequence x_seq (T, R, F) from h0 (R, H): returns (q (T, R, A), h_T).
+        On the GPU the input projection x @ W_ih^T of ALL steps is one GEMM and the head runs once
+        over the stacked hidden states; per step only h @ W_hh^T and the fused gate kernel remain
+        (the same `_thnn_fused_gru_cell` nn.GRUCell dispatches to, so the arithmetic per step is
+        GRUCell's)."""
+        T, R = x_seq.shape[0], x_seq.shape[1]
+        h = h0.reshape(-1, self.rnn_hidden_dim)
+        hs = []
+        if x_seq.is_cuda:
+            igates = torch.matmul(x_seq.reshape(T * R, -1), self.rnn.weight_ih.t()).view(T, R, -1)
+            w_hh_t = self.rnn.weight_hh.t()
+            for t in range(T):
+                h = torch.ops.aten._thnn_fused_gru_cell(igates[t], torch.matmul(h, w_hh_t), h, self.rnn.bias_ih, self.rnn.bias_hh)[0]
+                hs.append(h)
+        else:
+            for t in range(T):
+                h = self.rnn(x_seq[t], h)
+                hs.append(h)
+        q = self.fc1(torch.stack(hs, dim=0).view(T * R, -1)).view(T, R, -1)
+        return q, h
 
     def forward(self, inputs, hidden_state):
         """Reference signature: inputs (R, obs+n_actions) float32, hidden (R, H) -> (q, h)."""

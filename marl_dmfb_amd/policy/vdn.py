@@ -200,6 +200,12 @@ class VDN:
                                    None if la is None else la[1:T + 1].reshape(T * R, -1)).view(T, R, -1)
         self.eval_hidden = self.eval_hidden.to(self.device).reshape(R, -1)
         self.target_hidden = self.target_hidden.to(self.device).reshape(R, -1)
+        if hasattr(self.eval_rnn, 'recurrent_seq'):
+            q_e, self.eval_hidden = self.eval_rnn.recurrent_seq(x_eval, self.eval_hidden)
+            with torch.no_grad():
+                q_t, self.target_hidden = self.target_rnn.recurrent_seq(x_tgt, self.target_hidden)
+            # (T, B*n, A) -> (B, T, n, A)
+            return (q_e.view(T, B, n, -1).permute(1, 0, 2, 3), q_t.view(T, B, n, -1).permute(1, 0, 2, 3))
         q_evals, q_targets = [], []
         for t in range(T):
             q_eval, self.eval_hidden = self.eval_rnn.recurrent(x_eval[t], self.eval_hidden)

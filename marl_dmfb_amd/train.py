@@ -22,6 +22,7 @@ class Trainer:
         self.args = args
         self.agents = Agents(args)
         self.rolloutWorker = RolloutWorker(env, self.agents, args)
+        self.rolloutWorker.use_graph = bool(getattr(args, 'use_graph', False))
         self.buffer = ReplayBuffer(args, device=env.device)
         self.episode_rewards, self.episode_steps = [], []
         self.episode_constraints, self.success_rate, self.time_cost = [], [], []

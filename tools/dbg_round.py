@@ -13,11 +13,12 @@ E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 cfg = dict(width=10, length=10, n_agents=4, fov=9)
 env = VecDMFB(n_envs=E, seed=1, device='cuda:0', **cfg)
-args = make_args(device='cuda:0', n_envs=E, batch_size=B, train_time=1, buffer_size=4 * E, **env.get_env_info())
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+args = make_args(device='cuda:0', n_envs=E, batch_size=B, train_time=1, buffer_size=4 * E, use_graph=bool(G), **env.get_env_info())
 tr = Trainer(env, args)
 log('built')
 w = tr.rolloutWorker
-for r in range(3):
+for r in range(4):
     t = time.time()
     out = w.generate_episode()
     torch.cuda.synchronize()
