@@ -49,7 +49,8 @@ def parse():
     ap.add_argument('--batch_size', type=int, default=512, help='episodes per learn')
     ap.add_argument('--train_time', type=int, default=4, help='learns per round')
     ap.add_argument('--buffer_size', type=int, default=16384, help='episodes kept in the HBM replay buffer')
-    ap.add_argument('--no_graph', action='store_true', help='run the rollout eagerly instead of replaying a HIP graph')
+    ap.add_argument('--graph', action='store_true', help='replay the rollout as a captured HIP graph (the in-loop kernel '
+                    'timing of the roofline object is then taken from an eager pass after the timed region)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_tiers', action='store_true')
     ap.add_argument('--roofline_envs', type=int, default=262144, help='batch for the large-batch roofline figure')
@@ -164,10 +165,16 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = world > 1
+    # BENCH_DIST_BACKEND=gloo rehearses the multi-rank control flow with all ranks on one GPU
+    backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if dist:
-        torch.distributed.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', device_id=device)
+        else:
+            torch.distributed.init_process_group(backend)
 
     from marl_dmfb_amd.common.arguments import make_args
     from marl_dmfb_amd.env.dmfb import VecDMFB
@@ -177,7 +184,7 @@ def main():
     env = VecDMFB(n_envs=a.n_envs, seed=1234, env_id0=rank * a.n_envs, device=device, **cfg)
     args = make_args(drop_num=a.drop_num, width=a.width, length=a.length, fov=a.fov, device=str(device), dist=dist,
                      n_envs=a.n_envs, batch_size=a.batch_size, train_time=a.train_time, buffer_size=a.buffer_size,
-                     use_graph=not a.no_graph,
+                     use_graph=a.graph,
                      **env.get_env_info())
     torch.manual_seed(1234 + rank)
     trainer = Trainer(env, args)
@@ -196,13 +203,17 @@ def main():
     if dist:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    if not env.timing:  # graph replays do not re-record the events: time one eager episode of the same loop
+        trainer.rolloutWorker.use_graph = False
+        trainer.rolloutWorker.generate_episode()
+        torch.cuda.synchronize()
     kern_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in env.timing]
     env.timing = None
     tot = torch.tensor([float(played), dt], device=device, dtype=torch.float64)
     if dist:
-        p = tot[0:1].clone()
+        p = tot[0:1].clone() if backend == 'nccl' else tot[0:1].cpu()
         torch.distributed.all_reduce(p, op=torch.distributed.ReduceOp.SUM)
-        m = tot[1:2].clone()
+        m = tot[1:2].clone() if backend == 'nccl' else tot[1:2].cpu()
         torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)
         played_all, dt_max = float(p.item()), float(m.item())
     else:

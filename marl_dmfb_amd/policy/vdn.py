@@ -97,7 +97,12 @@ class VDN:
         """Same initial weights on every rank (one flat broadcast)."""
         params = list(self.eval_rnn.parameters())
         flat = torch.cat([p.data.reshape(-1) for p in params])
-        torch.distributed.broadcast(flat, src)
+        if flat.is_cuda and torch.distributed.get_backend() == 'gloo':
+            host = flat.cpu()
+            torch.distributed.broadcast(host, src)
+            flat = host.to(flat.device)
+        else:
+            torch.distributed.broadcast(flat, src)
         off = 0
         for p in params:
             p.data.copy_(flat[off:off + p.numel()].view_as(p))
@@ -115,7 +120,13 @@ class VDN:
             self._flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
             off += p.numel()
         self._flat[n] = mask_sum
-        torch.distributed.all_reduce(self._flat, op=torch.distributed.ReduceOp.SUM)
+        if self._flat.is_cuda and torch.distributed.get_backend() == 'gloo':
+            # rehearsal only (several ranks sharing one GPU over gloo): stage through the host
+            host = self._flat.cpu()
+            torch.distributed.all_reduce(host, op=torch.distributed.ReduceOp.SUM)
+            self._flat.copy_(host)
+        else:
+            torch.distributed.all_reduce(self._flat, op=torch.distributed.ReduceOp.SUM)
         total = self._flat[n]
         off = 0
         for p in params:
