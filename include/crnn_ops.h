@@ -1,0 +1,36 @@
+/*
+ * crnn_ops.h -- C ABI of the hand-written HIP inference kernel for the convolutional front end of
+ * the reference's per-agent Q-network `CRNN` (network/base_net.py:35-71): for fov 9 the stack is
+ * Conv2d(3->od,k3,s1)+ReLU -> Conv2d(od->od,k3,s1)+ReLU -> flatten (c,h,w) (base_net.py:23-33,63-65).
+ *
+ * Used by the vectorised rollout (agent/agent.py:22-48 batched over envs x agents): the observation
+ * rows are the int8 rows written by the env kernels, the output is the float32 feature block the GRU
+ * consumes.  Forward only (rollouts run under no_grad); training uses the autograd path.
+ * fp32 arithmetic, same products as torch.nn.functional.conv2d, different summation order.
+ */
+#ifndef CRNN_OPS_H
+#define CRNN_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRNN_OK 0
+#define CRNN_ERR_BAD_ARG (-1)
+#define CRNN_ERR_UNSUPPORTED (-6) /* only fov 9 with od 24 or 32 (the reference's 4d / other yaml values) */
+#define CRNN_ERR_HIP (-100)
+
+/* d_obs:  int8 [rows][obs_stride], first 243 bytes of a row = pixel block (3,9,9) in (c,x,y) order
+ * d_w1:   float32 [od][3][3][3]   d_b1: [od]      (conv1.weight / conv1.bias)
+ * d_w2:   float32 [od][od][3][3]  d_b2: [od]      (conv2.weight / conv2.bias)
+ * d_out:  float32 [rows][out_stride], first od*25 entries of a row are written, index c*25 + h*5 + w */
+int crnn_conv9_forward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_w1, const float *d_b1,
+                       const float *d_w2, const float *d_b2, int od, float *d_out, int64_t out_stride, void *stream);
+int crnn_last_hip_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -131,3 +131,15 @@ def meda_vec():
     lib.meda_vec_last_hip_error.argtypes = []
     lib._typed = True
     return lib
+
+
+def crnn_ops():
+    """include/crnn_ops.h"""
+    lib = load('crnn_ops')
+    if getattr(lib, '_typed', False):
+        return lib
+    vp, i64 = C.c_void_p, C.c_int64
+    lib.crnn_conv9_forward.argtypes = [vp, i64, i64, vp, vp, vp, vp, C.c_int, vp, i64, vp]
+    lib.crnn_last_hip_error.argtypes = []
+    lib._typed = True
+    return lib

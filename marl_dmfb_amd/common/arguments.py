@@ -91,7 +91,7 @@ def get_evaluate_args(argv=None):
     p.add_argument('--b-degrade', default=True)
     p.add_argument('--per-degrade', type=float, default=0)
     p.add_argument('--evaluate_epoch', type=int, default=20)
-    p.set_defaults(load_model=True)
+    p.set_defaults(load_model=True, n_envs=5)
     args = set_default(p.parse_args(argv))
     args.__dict__.update(_COMMON)
     args.hyper_hidden_dim = TRAIN_PARAS[('dmfb', 4)]['hyper_hidden_dim']  # evaluation reads 4d.yaml doc 1 (:130-133)
