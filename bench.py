@@ -57,7 +57,7 @@ def parse():
     return ap.parse_args()
 
 
-def env_only_tier(cfg, E, iters, device):
+def env_only_tier(cfg, E, iters, device, fov_kernel=False):
     """Env-only tier: fused transition kernel with auto-reset, uniform random actions."""
     from marl_dmfb_amd.env.dmfb import VecDMFB
     env = VecDMFB(n_envs=E, seed=1, device=device, **cfg)
@@ -75,9 +75,24 @@ def env_only_tier(cfg, E, iters, device):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     b = algo_bytes_per_env_step(cfg['n_agents'], cfg['fov'])
+    out = {'n_envs': E, 'us_per_launch': round(us, 2), 'env_steps_per_s': round(E / us * 1e6),
+           'algo_GBps': round(E * b / us / 1e3, 1), 'frac': round(E * b / us / 1e3 / HBM_PEAK_GBPS, 4)}
+    if fov_kernel:
+        # the FOV-gather kernel alone (k_observe): n*(3 fov^2 + 2) bytes written + 4n+... read per chip
+        env.observe()
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(iters):
+            env.observe()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        n, fov = cfg['n_agents'], cfg['fov']
+        fb = n * (3 * fov * fov + 2) + 5 * n + 8  # FOV-gather kernel alone
+        out['fov_kernel'] = {'kernel': 'dmfbk::k_observe<%d>' % n, 'us_per_launch': round(us, 2), 'algo_bytes_per_env': fb,
+                             'algo_GBps': round(E * fb / us / 1e3, 1), 'frac': round(E * fb / us / 1e3 / HBM_PEAK_GBPS, 4)}
     env.close()
-    return {'n_envs': E, 'us_per_launch': round(us, 2), 'env_steps_per_s': round(E / us * 1e6),
-            'algo_GBps': round(E * b / us / 1e3, 1), 'frac': round(E * b / us / 1e3 / HBM_PEAK_GBPS, 4)}
+    return out
 
 
 def cpu_baseline(cfg, args_ns, seconds=20.0):
@@ -255,7 +270,7 @@ def main():
         trainer = None
         torch.cuda.empty_cache()
         out['tiers'] = {'env_only_4096': env_only_tier(cfg, a.n_envs, 300, device),
-                        'env_only_large_batch': env_only_tier(cfg, a.roofline_envs, 100, device)}
+                        'env_only_large_batch': env_only_tier(cfg, a.roofline_envs, 100, device, fov_kernel=True)}
     if not a.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(cfg, a)
     print(json.dumps(out), flush=True)
