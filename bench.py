@@ -224,6 +224,16 @@ def main():
         torch.cuda.synchronize()
     kern_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in env.timing]
     env.timing = None
+    # an event pair with nothing between it still measures ~2-3 us of marker latency: calibrate and subtract,
+    # so that the figure is the kernel's own duration (what rocprofv3 --kernel-trace reports)
+    pairs = []
+    for _ in range(200):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    ev = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in pairs)
+    event_overhead_us = ev[len(ev) // 2]
     tot = torch.tensor([float(played), dt], device=device, dtype=torch.float64)
     if dist:
         p = tot[0:1].clone() if backend == 'nccl' else tot[0:1].cpu()
@@ -240,7 +250,8 @@ def main():
         return
 
     b = algo_bytes_per_env_step(a.drop_num, a.fov)
-    avg_us = sum(kern_us) / max(1, len(kern_us))
+    raw_us = sum(kern_us) / max(1, len(kern_us))
+    avg_us = max(raw_us - event_overhead_us, 0.1)
     achieved = a.n_envs * b / avg_us / 1e3  # GB/s
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -264,6 +275,7 @@ def main():
         'roofline': {'bound': 'hbm', 'kernel': 'dmfbk::k_step<%d,false>' % a.drop_num, 'achieved': round(achieved, 1),
                      'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4),
                      'traffic': traffic, 'launches_timed': len(kern_us), 'avg_launch_us': round(avg_us, 2),
+                     'event_pair_raw_us': round(raw_us, 2), 'event_overhead_us': round(event_overhead_us, 2),
                      'algo_bytes_per_env_step': b, 'envs_per_launch': a.n_envs},
     }
     if not a.no_tiers and world == 1:

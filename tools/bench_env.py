@@ -10,17 +10,24 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from marl_dmfb_amd.env.dmfb import VecDMFB  # noqa: E402
+from marl_dmfb_amd.env.meda import VecMEDA  # noqa: E402
 
 CFGS = {
     'A': dict(width=10, length=10, n_agents=4, fov=9),
     'D': dict(width=50, length=50, n_agents=10, fov=9),
     'E': dict(width=20, length=20, n_agents=10, fov=9, b_degrade=True, per_degrade=1.0),
+    # BASELINE config 3 is 'MEDA 10x10': rejected by the reference (meda.py:151-154); smallest legal 4-droplet chip
+    # and the CLI default chip instead
+    'M30': dict(width=30, length=30, n_agents=4, fov=19, meda=True),
+    'M60': dict(width=30, length=60, n_agents=4, fov=19, meda=True),
 }
 
 
 def algo_bytes(cfg, ext_uniforms=False):
     """algorithmic bytes per env-step."""
     n, fov = cfg['n_agents'], cfg['fov']
+    if cfg.get('meda'):
+        return n * (4 * fov * fov + 2) + 8 * n + n + 9 + n + 2 * (4 * n + 16)
     writes = n * (3 * fov * fov + 2) + 8 * n + n + 5
     reads = n + (8 * n if ext_uniforms else 0) + (8 * n if cfg.get('b_degrade') else 0)
     state = 2 * (2 * n + n + 8) + (4 * n if cfg.get('b_degrade') else 0)
@@ -28,11 +35,13 @@ def algo_bytes(cfg, ext_uniforms=False):
 
 
 def run(name, E, iters, autoreset=True):
-    cfg = CFGS[name]
-    env = VecDMFB(n_envs=E, seed=0, **cfg)
+    cfg = dict(CFGS[name])
+    meda = cfg.pop('meda', False)
+    env = (VecMEDA if meda else VecDMFB)(n_envs=E, seed=0, **cfg)
+    cfg['meda'] = meda
     env.reset()
     g = torch.Generator(device='cuda').manual_seed(0)
-    acts = [torch.randint(0, 5, (E, cfg['n_agents']), device='cuda', generator=g, dtype=torch.int8) for _ in range(8)]
+    acts = [torch.randint(0, 9 if meda else 5, (E, cfg['n_agents']), device='cuda', generator=g, dtype=torch.int8) for _ in range(8)]
     for i in range(10):
         env.step(acts[i % 8], autoreset=autoreset)
     torch.cuda.synchronize()
@@ -50,12 +59,12 @@ def run(name, E, iters, autoreset=True):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('--cfg', default='A,D,E')
+    ap.add_argument('--cfg', default='A,D,E,M30,M60')
     ap.add_argument('--sizes', default='4096,65536,262144,1048576')
     ap.add_argument('--iters', type=int, default=200)
     a = ap.parse_args()
     for name in a.cfg.split(','):
         for E in [int(s) for s in a.sizes.split(',')]:
-            if name != 'A' and E > 262144:
+            if name != 'A' and E > 262144 or name.startswith('M') and E > 65536:
                 continue
             print(json.dumps(run(name, E, a.iters)), flush=True)
