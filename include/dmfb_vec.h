@@ -39,6 +39,7 @@ extern "C" {
 
 #define DMFB_MAX_AGENTS 16  /* droplets per chip the kernels are instantiated for */
 #define DMFB_MAX_DIM 255    /* width/length limit (positions are packed in bytes) */
+#define DMFB_MAX_BLOCKS 64  /* 2x2 obstacle blocks per chip (one wave lane holds one block during generation) */
 
 /* dmfb_vec_step flags */
 #define DMFB_STEP_RECORD 1u     /* DMFBenv.step(record=True): addUsage                dmfb.py:570-571 */
@@ -106,6 +107,12 @@ int dmfb_vec_restart(dmfb_vec *h, const uint8_t *d_mask, int8_t *d_obs, void *st
  * d_starts, d_ends int32[E][n][2] (x, y). */
 int dmfb_vec_set_task(dmfb_vec *h, const int32_t *d_starts, const int32_t *d_ends, void *stream);
 int dmfb_vec_get_task(const dmfb_vec *h, int32_t *d_starts, int32_t *d_ends, void *stream);
+
+/* Obstacle injection = assigning routing_manager.blocks (dmfb.py:34-41,138): d_blocks int32[E][nb][4] =
+ * (x_min, x_max, y_min, y_max), nb <= the n_blocks the handle was created with; every chip gets nb blocks.
+ * get returns the current per-chip count through *nb_out (host int) and fills int32[E][n_blocks][4]. */
+int dmfb_vec_set_blocks(dmfb_vec *h, const int32_t *d_blocks, int nb, void *stream);
+int dmfb_vec_get_blocks(const dmfb_vec *h, int32_t *d_blocks, int *nb_out, void *stream);
 
 /* DMFBenv.step(actions, record) (dmfb.py:560-587) for all E envs.
  * d_uniforms: float64[E][n], entry [e][i] is the random.random() draw droplet i of env e

@@ -48,7 +48,7 @@ class DmfbVecStepOut(C.Structure):
 DMFB_VEC_SYMBOLS = [
     'dmfb_vec_check_config', 'dmfb_vec_create', 'dmfb_vec_destroy', 'dmfb_vec_state_bytes', 'dmfb_vec_obs_len',
     'dmfb_vec_max_step', 'dmfb_vec_n_envs', 'dmfb_vec_n_agents', 'dmfb_vec_reset', 'dmfb_vec_restart',
-    'dmfb_vec_set_task', 'dmfb_vec_get_task', 'dmfb_vec_step', 'dmfb_vec_observe', 'dmfb_vec_get_state',
+    'dmfb_vec_set_task', 'dmfb_vec_get_task', 'dmfb_vec_set_blocks', 'dmfb_vec_get_blocks', 'dmfb_vec_step', 'dmfb_vec_observe', 'dmfb_vec_get_state',
     'dmfb_vec_get_map', 'dmfb_vec_set_map', 'dmfb_vec_zoom_lut', 'dmfb_vec_strerror', 'dmfb_vec_last_hip_error',
 ]
 
@@ -70,6 +70,8 @@ def dmfb_vec():
     lib.dmfb_vec_restart.argtypes = [vp, vp, vp, vp]
     lib.dmfb_vec_set_task.argtypes = [vp, vp, vp, vp]
     lib.dmfb_vec_get_task.argtypes = [vp, vp, vp, vp]
+    lib.dmfb_vec_set_blocks.argtypes = [vp, vp, i32, vp]
+    lib.dmfb_vec_get_blocks.argtypes = [vp, vp, C.POINTER(C.c_int), vp]
     lib.dmfb_vec_step.argtypes = [vp, vp, vp, vp, u32, C.POINTER(DmfbVecStepOut), vp]
     lib.dmfb_vec_observe.argtypes = [vp, vp, vp, vp]
     lib.dmfb_vec_get_state.argtypes = [vp, vp, vp, vp, vp, vp]

@@ -42,6 +42,7 @@ enum : uint32_t { STREAM_MOVE = 1, STREAM_TASK = 2, STREAM_DEGRADE = 3, STREAM_B
 
 struct DevCfg {
     int W, L, fov, hf, ff, obs_len, max_step, stall, b_degrade, E, n;
+    int nb;     // obstacle blocks per chip currently in force (0 when none / skipped by the density rule)
     int T;      // chips per workgroup of the launch being made (k_step)
     int T_obs;  // chips per workgroup of k_observe
     uint32_t k0, k1, env_id0;
@@ -56,6 +57,7 @@ struct DevPtrs {
     double *degrade;   // [E][W*L]
     uint16_t *usage;   // [E][W*L]
     const int8_t *zoom;  // [2][511] direction zoom table
+    uint32_t *blocks;    // [n_blocks][E] x_min | x_max<<8 | y_min<<16 | y_max<<24, or nullptr
 };
 
 // ---- packed record layout -------------------------------------------------------------------
@@ -203,6 +205,46 @@ template <int N> __device__ __forceinline__ void task_to_env(const uint32_t (&pt
     }
 }
 
+// ---- obstacle generation: GenRandomBlocks (dmfb.py:228-251) --------------------------------------
+// Executed by a FULL wave after gen_task_wave (pts = the accepted 2N points, same in every lane).
+// Blocks are drawn one after another; for block b all 64 lanes test 64 attempts at once and the
+// lowest accepted attempt wins (= the serial loop).  Lane b keeps block b; returns this lane's block.
+template <int N>
+__device__ __forceinline__ uint32_t gen_blocks_wave(const DevCfg &c, uint32_t env_gid, uint32_t ep, const uint32_t (&pts)[N]) {
+    const int lane = lane_id();
+    uint32_t myblk = 0;
+    for (int b = 0; b < c.nb; ++b) {
+        for (uint32_t round = 0;; ++round) {
+            const bool last = round == kTaskMaxRounds - 1;
+            const uint32_t attempt = round * kWave + lane;
+            uint32_t w[4];
+            philox(c.k0, c.k1, env_gid, ep, attempt, (STREAM_BLOCK << 8) | (uint32_t)b, w);
+            const int y0 = below(w[0], c.L - 3), x0 = below(w[1], c.W - 3);
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < 2 * N; ++i) {  // Block.isPointInside over starts and ends
+                const uint32_t pi = (pts[i >> 1] >> (16 * (i & 1))) & 0xffff;
+                const int px = pi & 0xff, py = pi >> 8;
+                bad |= (px >= x0) & (px <= x0 + 1) & (py >= y0) & (py <= y0 + 1);
+            }
+            for (int k = 0; k < b; ++k) {  // Block.isBlockOverlap with the earlier blocks (dmfb.py:56-69)
+                const uint32_t o = (uint32_t)__shfl((int)myblk, k, kWave);
+                const int ox0 = o & 0xff, ox1 = (o >> 8) & 0xff, oy0 = (o >> 16) & 0xff, oy1 = o >> 24;
+                bad |= !(x0 > ox1 || ox0 > x0 + 1) && !(y0 > oy1 || oy0 > y0 + 1);
+            }
+            const unsigned long long acc = __ballot(!bad) | (last ? (1ull << (kWave - 1)) : 0ull);
+            if (acc) {
+                const int win = __ffsll((long long)acc) - 1;
+                const uint32_t cand = (uint32_t)x0 | ((uint32_t)(x0 + 1) << 8) | ((uint32_t)y0 << 16) | ((uint32_t)(y0 + 1) << 24);
+                const uint32_t chosen = (uint32_t)__shfl((int)cand, win, kWave);
+                if (lane == b) myblk = chosen;
+                break;
+            }
+        }
+    }
+    return myblk;
+}
+
 template <int N> __device__ __forceinline__ void store_starts(const DevPtrs &p, int E, int e, const int (&sx)[N], const int (&sy)[N]) {
 #pragma unroll
     for (int w = 0; w < Rec<N>::NP; ++w) p.starts[(size_t)w * E + e] = pack_pos<N>(sx, sy, w);
@@ -268,8 +310,8 @@ __device__ __forceinline__ void zero_tile(const Tile &t, int bytes16, int tid, i
 // Pass 1: one lane per row (layers 0/1 + direction).  Pass 2: one lane per (row, window row x) for
 // the out-of-chip bands of layer 2.
 template <int N>
-__device__ __forceinline__ void scatter_tile(const DevCfg &c, const DevPtrs &p, const Tile &t, int tv, int tid,
-                                             int nthreads) {
+__device__ __forceinline__ void scatter_tile(const DevCfg &c, const DevPtrs &p, const Tile &t, int tile_base, int tv,
+                                             int tid, int nthreads) {
     const int fov = c.fov, hf = c.hf, ff = c.ff;
     const int rows = tv * N;
     for (int it = tid; it < rows; it += nthreads) {
@@ -295,6 +337,16 @@ __device__ __forceinline__ void scatter_tile(const DevCfg &c, const DevPtrs &p, 
         }
         row[3 * ff] = p.zoom[(gp[i] & 0xff) - cx + 255];
         row[3 * ff + 1] = p.zoom[511 + (gp[i] >> 8) - cy + 255];
+    }
+    if (c.nb > 0) {  // layer 2: blocks, GLOBAL coordinates used as window coordinates (reference quirk dmfb.py:422-426)
+        for (int k = tid; k < rows * c.nb; k += nthreads) {
+            const int r = k / c.nb, b = k - r * c.nb;
+            const uint32_t o = p.blocks[(size_t)b * c.E + tile_base + r / N];
+            const int x0 = o & 0xff, x1 = (o >> 8) & 0xff, y0 = (o >> 16) & 0xff, y1 = o >> 24;
+            int8_t *row = t.obs + (size_t)r * c.obs_len + 2 * ff;
+            for (int i = x0; i <= x1 && i < fov; ++i)
+                for (int j = y0; j <= y1 && j < fov; ++j) row[i * fov + j] = 1;
+        }
     }
     for (int k = tid; k < rows * fov; k += nthreads) {  // layer 2: out-of-chip bands (dmfb.py:428-439)
         const int r = fov == 1 ? k : (int)__umulhi((uint32_t)k, c.fov_magic);
@@ -408,6 +460,26 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
                     }
                 }
             }
+            // _isTouchingBlocks (dmfb.py:301-308) of every droplet's TENTATIVE cell: it depends only on the
+            // droplet's own position and action, so it is evaluated up front, one pass over the blocks.
+            bool blocked[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) blocked[i] = false;
+            if (c.nb > 0) {
+                int tx[N], ty[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    int nx = r.x[i] + (acts[i] == 1) - (acts[i] == 2), ny = r.y[i] + (acts[i] == 4) - (acts[i] == 3);
+                    tx[i] = nx > c.W - 1 ? c.W - 1 : (nx < 0 ? 0 : nx);
+                    ty[i] = ny > c.L - 1 ? c.L - 1 : (ny < 0 ? 0 : ny);
+                }
+                for (int b = 0; b < c.nb; ++b) {
+                    const uint32_t o = p.blocks[(size_t)b * E + e];
+                    const int x0 = o & 0xff, x1 = (o >> 8) & 0xff, y0 = (o >> 16) & 0xff, y1 = o >> 24;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) blocked[i] |= (tx[i] >= x0) & (tx[i] <= x1) & (ty[i] >= y0) & (ty[i] <= y1);
+                }
+            }
             // ---- moveDroplets (dmfb.py:253-299)
             int code[N], pastx[N], pasty[N], sta[N], dyn[N];
             bool was_done[N];
@@ -429,6 +501,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
                         int nx = x0 + (act == 1) - (act == 2), ny = y0 + (act == 4) - (act == 3);  // Droplet.move (dmfb.py:103-124)
                         nx = nx > c.W - 1 ? c.W - 1 : (nx < 0 ? 0 : nx);
                         ny = ny > c.L - 1 ? c.L - 1 : (ny < 0 ? 0 : ny);
+                        if (blocked[i]) { nx = x0; ny = y0; }  // revert when touching a block (dmfb.py:338-340)
                         r.x[i] = nx; r.y[i] = ny;
                         bool clash = false;  // _isinvalidaction (dmfb.py:310-323)
                         if (dup) clash = any_dup<N>(r);
@@ -541,6 +614,10 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
             const uint32_t ep = (uint32_t)__shfl((int)r.rep, src, kWave);
             uint32_t pts[N];
             gen_task_wave<N>(c, gid, ep, pts);
+            if (c.nb > 0) {
+                const uint32_t blk = gen_blocks_wave<N>(c, gid, ep, pts);
+                if (lane < c.nb) p.blocks[(size_t)lane * E + (tile_base + wave * kWave + src)] = blk;
+            }
             if (lane == src) {
                 int sx[N], sy[N];
                 task_to_env<N>(pts, r, sx, sy);
@@ -575,7 +652,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
         }
     }
     if (!want_obs) return;
-    scatter_tile<N>(c, p, t, tv, tid, kBlock);
+    scatter_tile<N>(c, p, t, tile_base, tv, tid, kBlock);
     __syncthreads();
     copy_tile_out(t, a.out.d_obs, (size_t)tile_base * N * c.obs_len, tv * N * c.obs_len, tid, kBlock);
 }
@@ -611,7 +688,7 @@ __global__ __launch_bounds__(kBlock) void k_observe(DevCfg c, DevPtrs p, const u
     }
     zero_tile(t, (int)(align16((size_t)tv * N * c.obs_len) >> 4), tid, kBlock);
     __syncthreads();
-    scatter_tile<N>(c, p, t, tv, tid, kBlock);
+    scatter_tile<N>(c, p, t, tile_base, tv, tid, kBlock);
     __syncthreads();
     const int row_bytes = N * c.obs_len;
     if (all) {
@@ -658,6 +735,10 @@ __global__ __launch_bounds__(kBlock) void k_reset(DevCfg c, DevPtrs p, const uin
     uint32_t rmap = mode == 3 ? 0u : p.st[(size_t)R::W_RMAP * E + e];
     uint32_t pts[N];
     gen_task_wave<N>(c, c.env_id0 + (uint32_t)e, rep, pts);
+    if (c.nb > 0) {
+        const uint32_t blk = gen_blocks_wave<N>(c, c.env_id0 + (uint32_t)e, rep, pts);
+        if (lane < c.nb) p.blocks[(size_t)lane * E + e] = blk;
+    }
     if (lane == 0) {
         EnvR<N> r;
         int sx[N], sy[N];

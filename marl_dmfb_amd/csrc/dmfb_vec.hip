@@ -55,6 +55,25 @@ __global__ void k_get_task(DevCfg c, DevPtrs p, int32_t *starts, int32_t *ends) 
     }
 }
 
+__global__ void k_set_blocks(DevCfg c, DevPtrs p, const int32_t *blocks, int nb) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= c.E) return;
+    for (int b = 0; b < nb; ++b) {
+        const int32_t *q = blocks + ((size_t)e * nb + b) * 4;
+        p.blocks[(size_t)b * c.E + e] = (uint32_t)(q[0] & 0xff) | ((uint32_t)(q[1] & 0xff) << 8) | ((uint32_t)(q[2] & 0xff) << 16) |
+                                         ((uint32_t)(q[3] & 0xff) << 24);
+    }
+}
+__global__ void k_get_blocks(DevCfg c, DevPtrs p, int32_t *blocks, int cap) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= c.E) return;
+    for (int b = 0; b < c.nb; ++b) {
+        const uint32_t o = p.blocks[(size_t)b * c.E + e];
+        int32_t *q = blocks + ((size_t)e * cap + b) * 4;
+        q[0] = o & 0xff; q[1] = (o >> 8) & 0xff; q[2] = (o >> 16) & 0xff; q[3] = o >> 24;
+    }
+}
+
 __global__ void k_get_state(DevCfg c, DevPtrs p, int32_t *pos, int32_t *dist, int32_t *step_count, int64_t *cons) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= c.E) return;
@@ -222,7 +241,7 @@ int dmfb_vec_check_config(const dmfb_vec_config *c) {
     if (c->fov > (c->width < c->length ? c->width : c->length)) return DMFB_ERR_FOV_TOO_LARGE;
     if (c->n_agents > (int)((c->width + 1) * (c->length + 1) / 9)) return DMFB_ERR_TOO_MANY_DROPLETS;
     if (c->n_agents > DMFB_MAX_AGENTS || c->width > DMFB_MAX_DIM || c->length > DMFB_MAX_DIM || c->fov < 1 ||
-        c->n_blocks != 0)
+        c->n_blocks < 0 || c->n_blocks > DMFB_MAX_BLOCKS)
         return DMFB_ERR_UNSUPPORTED;
     if (c->n_envs <= 0) return DMFB_ERR_BAD_ARG;
     if (tile_lds_bytes(16, c->n_agents, 3 * c->fov * c->fov + 2, true) > 64 * 1024) return DMFB_ERR_UNSUPPORTED;
@@ -264,6 +283,14 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
         CREATE_TRY(hipMalloc(&h->dp.usage, cells * E * 2));
         h->bytes += cells * E * 18;
     }
+    // GenRandomBlocks guards (dmfb.py:230-234): no blocks on tiny chips or above 20 % coverage
+    d.nb = cfg->n_blocks;
+    if (cfg->width < 5 || cfg->length < 5 || (double)(cfg->n_blocks * 4) / (double)(cfg->width * cfg->length) > 0.2) d.nb = 0;
+    if (cfg->n_blocks > 0) {
+        CREATE_TRY(hipMalloc(&h->dp.blocks, (size_t)cfg->n_blocks * E * 4));
+        CREATE_TRY(hipMemsetAsync(h->dp.blocks, 0, (size_t)cfg->n_blocks * E * 4, s));
+        h->bytes += (size_t)cfg->n_blocks * E * 4;
+    }
     for (int dd = -255; dd <= 255; ++dd) {
         int zx = dd, zy = dd;
         if (d.hf != 10) { zx = zoom_one(dd, d.hf, d.W); zy = zoom_one(dd, d.hf, d.L); }
@@ -295,7 +322,7 @@ int dmfb_vec_destroy(dmfb_vec *h) {
     if (!h) return DMFB_OK;
     DeviceGuard g(h->cfg.device);
     (void)hipFree(h->dp.st); (void)hipFree(h->dp.starts); (void)hipFree(h->dp.health);
-    (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage); (void)hipFree(h->zoom_dev);
+    (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage); (void)hipFree(h->zoom_dev); (void)hipFree(h->dp.blocks);
     delete h;
     return DMFB_OK;
 }
@@ -338,6 +365,30 @@ int dmfb_vec_get_task(const dmfb_vec *h, int32_t *d_starts, int32_t *d_ends, voi
     (void)hipGetLastError();  // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(k_get_task, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dc, h->dp,
                        d_starts, d_ends);
+    HIP_TRY(hipGetLastError());
+    return DMFB_OK;
+}
+
+int dmfb_vec_set_blocks(dmfb_vec *h, const int32_t *d_blocks, int nb, void *stream) {
+    if (!h || nb < 0 || nb > h->cfg.n_blocks || (nb > 0 && !d_blocks)) return DMFB_ERR_BAD_ARG;
+    DeviceGuard g(h->cfg.device);
+    h->dc.nb = nb;
+    if (nb == 0) return DMFB_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_set_blocks, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dc, h->dp,
+                       d_blocks, nb);
+    HIP_TRY(hipGetLastError());
+    return DMFB_OK;
+}
+
+int dmfb_vec_get_blocks(const dmfb_vec *h, int32_t *d_blocks, int *nb_out, void *stream) {
+    if (!h) return DMFB_ERR_BAD_ARG;
+    if (nb_out) *nb_out = h->dc.nb;
+    if (!d_blocks || h->dc.nb == 0) return DMFB_OK;
+    DeviceGuard g(h->cfg.device);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_get_blocks, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->dc, h->dp,
+                       d_blocks, h->cfg.n_blocks);
     HIP_TRY(hipGetLastError());
     return DMFB_OK;
 }

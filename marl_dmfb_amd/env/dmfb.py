@@ -61,6 +61,7 @@ class VecDMFB:
             raise RuntimeError('VecDMFB runs on the GPU only (no CPU fallback)')
         self.width, self.length, self.n_agents, self.fov = width, length, n_agents, fov
         self.n_envs, self.stall, self.b_degrade = n_envs, bool(stall), bool(b_degrade)
+        self.n_blocks = n_blocks
         self.has_maps = bool(b_degrade or with_maps)
         self.cfg = _lib.DmfbVecConfig(width, length, n_agents, n_blocks, fov, int(bool(stall)), int(bool(b_degrade)),
                                       int(bool(with_maps)), float(per_degrade), n_envs, env_id0, seed,
@@ -143,6 +144,17 @@ class VecDMFB:
         e = torch.empty_like(s)
         _check(self.lib.dmfb_vec_get_task(self.h, _ptr(s), _ptr(e), self._stream()))
         return s, e
+
+    def set_blocks(self, blocks):
+        """Obstacle injection: blocks [E, nb, 4] = (x_min, x_max, y_min, y_max) (dmfb.py:34-41)."""
+        b = self._dev(blocks, torch.int32).reshape(self.n_envs, -1, 4)
+        _check(self.lib.dmfb_vec_set_blocks(self.h, _ptr(b) if b.shape[1] else None, b.shape[1], self._stream()))
+
+    def get_blocks(self):
+        nb = C.c_int(0)
+        buf = torch.zeros((self.n_envs, max(1, self.n_blocks), 4), dtype=torch.int32, device=self.device)
+        _check(self.lib.dmfb_vec_get_blocks(self.h, _ptr(buf), C.byref(nb), self._stream()))
+        return buf[:, :nb.value]
 
     # ------------------------------------------------------------------ transition
     def step(self, actions, uniforms=None, record=True, autoreset=False, active=None, out=None):

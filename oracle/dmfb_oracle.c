@@ -229,7 +229,7 @@ static void gen_blocks(dmfb_oracle *o, dmfb_env *e) {
             for (int k = 0; k < e->nblk && !bad; ++k) /* Block.isBlockOverlap: dmfb.py:56-69 */
                 if (!(x0 > e->blk[k][1] || e->blk[k][0] > x0 + 1) &&
                     !(y0 > e->blk[k][3] || e->blk[k][2] > y0 + 1)) bad = 1;
-            if (!bad) {
+            if (!bad || attempt == DMFB_TASK_MAX_ATTEMPTS - 1) { /* bounded like the kernels */
                 e->blk[e->nblk][0] = x0; e->blk[e->nblk][1] = x0 + 1;
                 e->blk[e->nblk][2] = y0; e->blk[e->nblk][3] = y0 + 1;
                 e->nblk++;
@@ -362,6 +362,14 @@ int dmfb_oracle_set_blocks(dmfb_oracle *o, const int32_t *blocks, int nb) {
             for (int c = 0; c < 4; ++c) e->blk[b][c] = blocks[(k * nb + b) * 4 + c];
     }
     return DMFB_OK;
+}
+
+/* blocks int32 [E][cap][4]; returns the per-env block count (identical for all envs) */
+int dmfb_oracle_get_blocks(const dmfb_oracle *o, int32_t *blocks, int cap) {
+    for (int k = 0; k < o->E; ++k)
+        for (int b = 0; b < o->envs[k].nblk && b < cap; ++b)
+            for (int c = 0; c < 4; ++c) blocks[((size_t)k * cap + b) * 4 + c] = o->envs[k].blk[b][c];
+    return o->envs[0].nblk;
 }
 
 void dmfb_oracle_get_task(const dmfb_oracle *o, int32_t *starts, int32_t *ends) {

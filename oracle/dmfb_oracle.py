@@ -49,6 +49,7 @@ def lib():
         L.dmfb_oracle_set_task.argtypes = [vp, vp, vp]
         L.dmfb_oracle_set_task.restype = None
         L.dmfb_oracle_set_blocks.argtypes = [vp, vp, i32]
+        L.dmfb_oracle_get_blocks.argtypes = [vp, vp, i32]
         L.dmfb_oracle_get_task.argtypes = [vp, vp, vp]
         L.dmfb_oracle_get_task.restype = None
         L.dmfb_oracle_get_state.argtypes = [vp, vp, vp, vp, vp]
@@ -118,6 +119,12 @@ class DmfbOracle:
     def set_blocks(self, blocks):
         b = np.ascontiguousarray(blocks, dtype=np.int32).reshape(self.E, -1, 4)
         _check(lib().dmfb_oracle_set_blocks(self.h, _p(b), b.shape[1]))
+
+    def get_blocks(self):
+        cap = max(1, self.n_blocks)
+        b = np.zeros((self.E, cap, 4), np.int32)
+        nb = lib().dmfb_oracle_get_blocks(self.h, _p(b), cap)
+        return b[:, :nb]
 
     def get_task(self):
         s = np.zeros((self.E, self.n, 2), np.int32)

@@ -27,9 +27,12 @@ def replay_independent(g, make_backend):
     ep_len = g['ep_len'].astype(int)
     E = len(ep_len)
     has_health = 'health' in g
-    B = make_backend(width=W, length=L, n_agents=n, fov=fov, stall=bool(stall), n_envs=E, with_maps=has_health)
+    nb = g['blocks'].shape[1] if 'blocks' in g else 0
+    B = make_backend(width=W, length=L, n_agents=n, fov=fov, stall=bool(stall), n_envs=E, with_maps=has_health, n_blocks=nb)
     if has_health:
         B.set_map('health', g['health'])
+    if nb:
+        B.set_blocks(g['blocks'])
     B.set_task(g['starts'], g['ends'])
     np.testing.assert_array_equal(B.observe(), g['obs0'])
     first = np.concatenate([[0], np.cumsum(ep_len)[:-1]])

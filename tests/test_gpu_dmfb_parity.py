@@ -74,6 +74,8 @@ def _lockstep(cfg, E, steps, seed, autoreset, record=True, act_dtype=np.int32, g
                 V.last_obs = V.v.obs.cpu().numpy()
             n_eps += int(term.sum())
         np.testing.assert_array_equal(O.observe(), V.last_obs, err_msg='obs t=%d' % t)
+        if cfg.get('n_blocks') and (t % 16 == 0 or term.any()):
+            np.testing.assert_array_equal(O.get_blocks(), V.get_blocks(), err_msg='blocks t=%d' % t)
         sv_ = V.get_state()
         so_ = O.get_state()
         for k in ('pos', 'dist', 'step_count', 'constraints'):
@@ -165,3 +167,25 @@ def test_lockstep_split_launch_path(monkeypatch):
     _lockstep(D, E=300, steps=230, seed=53, autoreset=True, greedy=0.9)
     _lockstep(Ecfg, E=333, steps=150, seed=54, autoreset=True, greedy=0.8)
     _lockstep(dict(width=12, length=9, n_agents=3, fov=7, with_maps=True), E=100, steps=60, seed=55, autoreset=True)
+
+
+def test_lockstep_with_obstacle_blocks():
+    """GenRandomBlocks (dmfb.py:228-251) through the Philox contract, _isTouchingBlocks and the block
+    layer of the observation, fused and split launch shapes."""
+    assert _lockstep(dict(A, n_blocks=4), E=600, steps=120, seed=61, autoreset=True) > 300
+    _lockstep(dict(A, n_blocks=5), E=77, steps=90, seed=62, autoreset=False)
+    _lockstep(dict(width=20, length=20, n_agents=6, fov=9, n_blocks=14), E=150, steps=170, seed=63, autoreset=True, greedy=0.85)
+    _lockstep(dict(Ecfg, n_blocks=8), E=96, steps=120, seed=64, autoreset=True, greedy=0.8)
+
+
+def test_lockstep_blocks_split_launch(monkeypatch):
+    monkeypatch.setenv('DMFB_VEC_SPLIT_MIN_ENVS', '1')
+    _lockstep(dict(A, n_blocks=4), E=300, steps=90, seed=65, autoreset=True)
+    _lockstep(dict(width=20, length=20, n_agents=6, fov=9, n_blocks=14), E=100, steps=100, seed=66, autoreset=False)
+
+
+def test_block_density_rule_matches_reference():
+    # GenRandomBlocks returns without blocks above 20 % coverage (dmfb.py:232-234): 6 blocks on 10x10 = 24 %
+    v = _vec(width=10, length=10, n_agents=2, fov=5, n_blocks=6, n_envs=4)
+    o = DmfbOracle(10, 10, 2, n_blocks=6, fov=5, n_envs=4)
+    assert v.get_blocks().shape[1] == 0 and o.get_blocks().shape[1] == 0

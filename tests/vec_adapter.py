@@ -20,6 +20,12 @@ class VecAdapter:
     def set_task(self, starts, ends):
         self.v.set_task(np.asarray(starts, np.int32), np.asarray(ends, np.int32))
 
+    def set_blocks(self, blocks):
+        self.v.set_blocks(np.asarray(blocks, np.int32))
+
+    def get_blocks(self):
+        return self.v.get_blocks().cpu().numpy()
+
     def get_task(self):
         s, e = self.v.get_task()
         return s.cpu().numpy(), e.cpu().numpy()

@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ref_shim  # noqa: E402
 
 ref_shim.install()
-from env.DMFB.dmfb import DMFBenv  # noqa: E402
+from env.DMFB.dmfb import DMFBenv, Block  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 'tests', 'golden')
 QUEUE = ref_shim.DrawQueue()
@@ -143,6 +143,41 @@ def gen_plain(name, W, L, n, fov, n_episodes, seed, stall=True, with_health=Fals
     finish(name, dict(W=W, L=L, n=n, fov=fov, stall=stall, b_degrade=False), rec, ep)
 
 
+def random_blocks(rng, W, L, nb, starts, ends):
+    """nb 2x2 blocks that respect GenRandomBlocks' rules (dmfb.py:243-251): no start/end inside, no overlap."""
+    pts = np.vstack((starts, ends))
+    blocks = []
+    while len(blocks) < nb:
+        x0, y0 = int(rng.integers(0, W - 3)), int(rng.integers(0, L - 3))
+        if any(x0 <= px <= x0 + 1 and y0 <= py <= y0 + 1 for px, py in pts):
+            continue
+        if any(not (x0 > b[1] or b[0] > x0 + 1) and not (y0 > b[3] or b[2] > y0 + 1) for b in blocks):
+            continue
+        blocks.append((x0, x0 + 1, y0, y0 + 1))
+    return blocks
+
+
+def gen_blocks(name, W, L, n, fov, nb, n_episodes, seed):
+    """Episodes with obstacle blocks assigned to routing_manager.blocks (dmfb.py:138): exercises
+    _isTouchingBlocks (dmfb.py:301-308,338-340) and the global-coordinates block layer of the
+    observation (dmfb.py:422-426)."""
+    rng = np.random.default_rng(seed)
+    env = DMFBenv(W, L, n, nb, fov=fov)
+    rm = env.routing_manager
+    rec, ep = new_rec(), {k: [] for k in ['starts', 'ends', 'ep_len', 'obs0', 'blocks']}
+    for k in range(n_episodes):
+        s, e = random_task(rng, W, L, n, spaced=True)
+        blocks = random_blocks(rng, W, L, nb, s, e)
+        rm.blocks = [Block(*b) for b in blocks]
+        rm.m_health = np.ones((W, L))
+        obs0 = inject_task(env, s, e)
+        ep['starts'].append(np.array(s, np.int16)); ep['ends'].append(np.array(e, np.int16))
+        ep['blocks'].append(np.array(blocks, np.int16))
+        ep['obs0'].append(np.stack(obs0).astype(np.int8))
+        ep['ep_len'].append(np.int32(run_episode(rng, env, rec, mode=k % 2, exact_prob=0.0)))
+    finish(name, dict(W=W, L=L, n=n, fov=fov, stall=True, b_degrade=False), rec, ep)
+
+
 def gen_degrade_chain(name, W, L, n, fov, n_episodes, seed):
     """evaDegre.py-style chain: ONE ageing chip, b_degrade=True, per_degrade=1.0,
     reset(new=False) between episodes so updateHealth (dmfb.py:465-471) fires.  Usage is
@@ -181,6 +216,10 @@ def crafted_A():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'blocks':
+        gen_blocks('F_10x10_4d_fov9_5blocks', 10, 10, 4, 9, 5, n_episodes=60, seed=401)
+        gen_blocks('F_20x20_10d_fov9_12blocks', 20, 20, 10, 9, 12, n_episodes=12, seed=402)
+        sys.exit(0)
     gen_plain('A_10x10_4d_fov9', 10, 10, 4, 9, n_episodes=120, seed=101, crafted=crafted_A())
     gen_plain('A_10x10_4d_fov9_health', 10, 10, 4, 9, n_episodes=60, seed=102, with_health=True)
     gen_plain('A_10x10_4d_fov9_nostall', 10, 10, 4, 9, n_episodes=40, seed=103, stall=False)
@@ -190,3 +229,5 @@ if __name__ == '__main__':
     gen_plain('D_50x50_10d_fov9', 50, 50, 10, 9, n_episodes=16, seed=201)
     gen_plain('E_20x20_10d_fov9_health', 20, 20, 10, 9, n_episodes=24, seed=301, with_health=True)
     gen_degrade_chain('E_20x20_10d_degrade_chain', 20, 20, 10, 9, n_episodes=24, seed=1)
+    gen_blocks('F_10x10_4d_fov9_5blocks', 10, 10, 4, 9, 5, n_episodes=60, seed=401)
+    gen_blocks('F_20x20_10d_fov9_12blocks', 20, 20, 10, 9, 12, n_episodes=12, seed=402)
