@@ -54,6 +54,8 @@ typedef struct {
     uint32_t env_id0;
     uint64_t seed;
     int32_t device;
+    int32_t obs_version; /* 0: MEDAEnv.getOneObs (4 layers, meda.py:613-674); 2: MEDAEnv_v0_2.getOneObs (3 int8 layers +
+                            direction zoomed to 30x30, meda.py:850-897; the CLI default version is '0.2') */
 } meda_vec_config;
 
 typedef struct {
@@ -61,7 +63,7 @@ typedef struct {
     uint8_t *d_dones;      /* [E][n]                                           meda.py:529-537 */
     double *d_fail;        /* [E]    info['constraints'] = np.sum(punish) <= 0 meda.py:256,538 */
     uint8_t *d_success;    /* [E]    info['success']                           meda.py:530-531 */
-    int8_t *d_obs;         /* [E][n][4*fov*fov+2] (the reference returns float64; values are small ints) */
+    int8_t *d_obs;         /* [E][n][obs_len] (version 0: the reference returns float64 holding small ints) */
     double *d_team_reward; /* [E]    np.sum(rewards)/n                         common/rollout.py:33 */
     uint8_t *d_terminated; /* [E]    all(dones)                                common/rollout.py:34-35 */
 } meda_vec_step_out;
@@ -70,7 +72,7 @@ int meda_vec_check_config(const meda_vec_config *cfg);               /* meda.py:
 int meda_vec_create(const meda_vec_config *cfg, void *stream, meda_vec **out); /* MEDAEnv.__init__ meda.py:469-510 */
 int meda_vec_destroy(meda_vec *h);
 size_t meda_vec_state_bytes(const meda_vec *h);
-int meda_vec_obs_len(const meda_vec *h);  /* 4*fov*fov+2  (get_env_info()['obs_shape'], meda.py:676-681) */
+int meda_vec_obs_len(const meda_vec *h);  /* 4*fov*fov+2 (obs_version 0, meda.py:676-681) or 3*fov*fov+2 (obs_version 2) */
 int meda_vec_max_step(const meda_vec *h); /* width+length (meda.py:492) */
 int meda_vec_n_envs(const meda_vec *h);
 int meda_vec_n_agents(const meda_vec *h);

@@ -89,7 +89,7 @@ class MedaVecConfig(C.Structure):
     """include/meda_vec.h: meda_vec_config"""
     _fields_ = [('width', C.c_int32), ('length', C.c_int32), ('n_agents', C.c_int32), ('fov', C.c_int32),
                 ('b_degrade', C.c_int32), ('with_maps', C.c_int32), ('per_degrade', C.c_double), ('n_envs', C.c_int32),
-                ('env_id0', C.c_uint32), ('seed', C.c_uint64), ('device', C.c_int32)]
+                ('env_id0', C.c_uint32), ('seed', C.c_uint64), ('device', C.c_int32), ('obs_version', C.c_int32)]
 
 
 class MedaVecStepOut(C.Structure):

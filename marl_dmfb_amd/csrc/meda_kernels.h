@@ -28,7 +28,7 @@ constexpr uint32_t kTaskMaxDraws = 1u << 20; // bound on rejection sampling (sam
 enum : uint32_t { STREAM_MOVE = 1, STREAM_DEGRADE = 3, STREAM_MEDA_TASK = 5 };
 
 struct MCfg {
-    int W, L, fov, ff, obs_len, max_step, b_degrade, E, n, T;
+    int W, L, fov, ff, obs_len, max_step, b_degrade, E, n, T, version;
     uint32_t k0, k1, env_id0;
     double per_healthy;
 };
@@ -39,6 +39,7 @@ struct MPtrs {
     double *degrade;
     uint16_t *usage;
     uint8_t *reset_flag;  // [E] chips auto-reset by the last step (updateHealth follow-up)
+    const int8_t *zoom;   // [2][256] v0_2 direction tables: round(d/(width/30)), round(d/(length/30)), index d+128
 };
 struct MStepArgs {
     const void *actions;

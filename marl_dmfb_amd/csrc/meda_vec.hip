@@ -3,6 +3,7 @@
 // meda_vec_n.hip.  Device code of the transition: meda_kernels.h.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -64,6 +65,67 @@ __global__ __launch_bounds__(kBlock) void k_meda_observe(MCfg c, MPtrs p, const 
         const int ox = cx - fov / 2, oy = cy - fov / 2;
         const int kx = k % 5 - kR, ky = k / 5 - kR;
         int8_t *row = tile + (size_t)rr * c.obs_len;
+        if (c.version == 2) {
+            // ---- MEDAEnv_v0_2.getOneObs (meda.py:850-897)
+            const int hf = fov / 2;
+            // members of the `observed` set: droplets with at least one footprint cell inside the window
+            uint32_t obs_mask = 0;
+            for (int j = 0; j < n; ++j) {
+                const uint32_t wj = words[s * n + j];
+                const int xj = wj & 0xff, yj = (wj >> 8) & 0xff;
+                const bool vis = (xj + kR >= ox) && (xj - kR <= ox + fov - 1) && (yj + kR >= oy) && (yj - kR <= oy + fov - 1);
+                obs_mask |= (uint32_t)vis << j;
+                if (on) {  // layer 0: every droplet, ascending index
+                    const int nx = xj + kx - ox, ny = yj + ky - oy;
+                    if (nx >= 0 && nx < fov && ny >= 0 && ny < fov) row[ny * fov + nx] = (int8_t)(j + 1);
+                }
+            }
+            // iteration order of the CPython set (see oracle/meda_oracle.c): ascending once it has had 5
+            // members (table resized to 32 slots), else slot order of the 8-slot table
+            unsigned long long order = 0;  // 4-bit entries
+            int cnt = 0;
+            if (__popc(obs_mask) >= 5) {
+                for (int j = 0; j < n; ++j)
+                    if ((obs_mask >> j) & 1) { order |= (unsigned long long)j << (4 * cnt); ++cnt; }
+            } else {
+                unsigned long long slots = 0;  // 8 x (valid bit | 4-bit value)
+                for (int j = 0; j < n; ++j)
+                    if ((obs_mask >> j) & 1) {
+                        int i = j & 7;
+                        while ((slots >> (5 * i)) & 16) i = (i * 5 + 1) & 7;
+                        slots |= (unsigned long long)(16 | j) << (5 * i);
+                    }
+                for (int i = 0; i < 8; ++i)
+                    if ((slots >> (5 * i)) & 16) { order |= ((slots >> (5 * i)) & 15) << (4 * cnt); ++cnt; }
+            }
+            for (int tt = 0; tt < cnt; ++tt) {  // layer 1: clipped goals of the observed OTHER droplets
+                const int j = (int)((order >> (4 * tt)) & 15);
+                if (on && j != a) {
+                    const uint32_t wj = words[s * n + j];
+                    int mx = (int)((wj >> 16) & 0xff) + kx - ox, my = (int)(wj >> 24) + ky - oy;
+                    mx = mx < 0 ? 0 : (mx > fov - 1 ? fov - 1 : mx);
+                    my = my < 0 ? 0 : (my > fov - 1 ? fov - 1 : my);
+                    row[ff + my * fov + mx] = (int8_t)(j + 1);
+                }
+            }
+            if (r < rows) {  // layer 2: boundary bands with the reference's axis mix-up (meda.py:880-890)
+                const int left = hf - cx, right = hf - (c.W - 1 - cx);
+                const int up = hf - cy, down = hf - (c.L - 1 - cy);
+                int c0 = 0, c1 = 0;
+                if (up > 0) { c0 = 0; c1 = up < fov ? up : fov; }
+                else if (down > 0) { c0 = fov - down < 0 ? 0 : fov - down; c1 = fov; }
+                for (int rr = k; rr < fov; rr += 32) {
+                    const bool full = left > 0 ? (rr < left) : (right > 0 ? (rr >= fov - right) : false);
+                    const int b0 = full ? 0 : c0, b1 = full ? fov : c1;
+                    for (int cc = b0; cc < b1; ++cc) row[2 * ff + rr * fov + cc] = 1;
+                }
+                if (k == 0) {
+                    row[3 * ff] = p.zoom[gya - cy + 128];
+                    row[3 * ff + 1] = p.zoom[256 + gxa - cx + 128];
+                }
+            }
+            continue;
+        }
         if (on) {
             {   // layer 0: own footprint
                 const int nx = cx + kx - ox, ny = cy + ky - oy;
@@ -231,6 +293,8 @@ struct meda_vec {
     MPtrs dp;
     size_t bytes = 0;
     size_t obs_lds = 0;
+    int8_t zoom_host[512];
+    int8_t *zoom_dev = nullptr;
 };
 
 namespace {
@@ -280,6 +344,7 @@ int meda_vec_check_config(const meda_vec_config *c) {
     if (c->n_agents > (c->width / 15) * (c->length / 15)) return MEDA_ERR_TOO_MANY_DROPLETS;
     if (c->n_agents > MEDA_MAX_AGENTS || c->width > MEDA_MAX_DIM || c->length > MEDA_MAX_DIM || c->fov < 1) return MEDA_ERR_UNSUPPORTED;
     if ((size_t)c->n_agents * (4 * c->fov * c->fov + 2) + 64 + (size_t)c->n_agents * 4 > 60 * 1024) return MEDA_ERR_UNSUPPORTED;
+    if (c->obs_version != 0 && c->obs_version != 2) return MEDA_ERR_UNSUPPORTED;
     if (c->n_envs <= 0) return MEDA_ERR_BAD_ARG;
     return MEDA_OK;
 }
@@ -294,7 +359,8 @@ int meda_vec_create(const meda_vec_config *cfg, void *stream, meda_vec **out) {
     if (!h) return MEDA_ERR_BAD_ARG;
     h->cfg = *cfg;
     MCfg &d = h->dc;
-    d.W = cfg->width; d.L = cfg->length; d.fov = cfg->fov; d.ff = cfg->fov * cfg->fov; d.obs_len = 4 * d.ff + 2;
+    d.W = cfg->width; d.L = cfg->length; d.fov = cfg->fov; d.ff = cfg->fov * cfg->fov;
+    d.version = cfg->obs_version; d.obs_len = (cfg->obs_version == 2 ? 3 : 4) * d.ff + 2;
     d.max_step = cfg->width + cfg->length; d.b_degrade = cfg->b_degrade != 0; d.E = cfg->n_envs; d.n = cfg->n_agents;
     d.k0 = (uint32_t)cfg->seed; d.k1 = (uint32_t)(cfg->seed >> 32); d.env_id0 = cfg->env_id0;
     d.per_healthy = 1.0 - cfg->per_degrade;
@@ -317,6 +383,13 @@ int meda_vec_create(const meda_vec_config *cfg, void *stream, meda_vec **out) {
     h->bytes = st_bytes + starts_bytes + E;
     CREATE_TRY(hipMemsetAsync(h->dp.st, 0, st_bytes, s));
     CREATE_TRY(hipMemsetAsync(h->dp.reset_flag, 0, (size_t)E, s));
+    for (int dd = -128; dd <= 127; ++dd) {  // python round() = half to even on the double quotient (meda.py:894)
+        h->zoom_host[dd + 128] = (int8_t)(int)std::nearbyint((double)dd / ((double)cfg->width / 30.0));
+        h->zoom_host[256 + dd + 128] = (int8_t)(int)std::nearbyint((double)dd / ((double)cfg->length / 30.0));
+    }
+    CREATE_TRY(hipMalloc(&h->zoom_dev, sizeof(h->zoom_host)));
+    CREATE_TRY(hipMemcpyAsync(h->zoom_dev, h->zoom_host, sizeof(h->zoom_host), hipMemcpyHostToDevice, s));
+    h->dp.zoom = h->zoom_dev;
     if (cfg->b_degrade || cfg->with_maps) {
         CREATE_TRY(hipMalloc(&h->dp.health, cells * E * 8));
         CREATE_TRY(hipMalloc(&h->dp.degrade, cells * E * 8));
@@ -330,6 +403,7 @@ int meda_vec_create(const meda_vec_config *cfg, void *stream, meda_vec **out) {
     rc = launch_reset(h, nullptr, 3, s);
     if (rc) { meda_vec_destroy(h); return rc; }
     CREATE_TRY(hipMemsetAsync(h->dp.reset_flag, 0, (size_t)E, s));  // construction does not run updateHealth
+    CREATE_TRY(hipStreamSynchronize(s));  // the zoom table upload reads host memory owned by the handle
     *out = h;
     return MEDA_OK;
 }
@@ -338,7 +412,7 @@ int meda_vec_destroy(meda_vec *h) {
     if (!h) return MEDA_OK;
     DeviceGuard g(h->cfg.device);
     (void)hipFree(h->dp.st); (void)hipFree(h->dp.starts); (void)hipFree(h->dp.reset_flag);
-    (void)hipFree(h->dp.health); (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage);
+    (void)hipFree(h->dp.health); (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage); (void)hipFree(h->zoom_dev);
     delete h;
     return MEDA_OK;
 }

@@ -45,7 +45,7 @@ class VecMEDA:
     plus n_envs / seed / env_id0 / with_maps)."""
 
     def __init__(self, width, length, n_agents, n_blocks=0, fov=19, stall=True, b_degrade=False, per_degrade=0.1,
-                 n_envs=1, seed=0, with_maps=False, env_id0=0, device=None):
+                 n_envs=1, seed=0, with_maps=False, env_id0=0, device=None, version=0):
         self.lib = _lib.meda_vec()
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
@@ -54,12 +54,13 @@ class VecMEDA:
             raise RuntimeError('VecMEDA runs on the GPU only (no CPU fallback)')
         self.width, self.length, self.n_agents, self.fov, self.n_envs = width, length, n_agents, fov, n_envs
         self.cfg = _lib.MedaVecConfig(width, length, n_agents, fov, int(bool(b_degrade)), int(bool(with_maps)),
-                                      float(per_degrade), n_envs, env_id0, seed, self.device.index or 0)
+                                      float(per_degrade), n_envs, env_id0, seed, self.device.index or 0, int(version))
+        self.version = int(version)
         _check(self.lib.meda_vec_check_config(C.byref(self.cfg)))
         self.h = C.c_void_p()
         with torch.cuda.device(self.device):
             _check(self.lib.meda_vec_create(C.byref(self.cfg), self._stream(), C.byref(self.h)))
-        self.obs_len = 4 * fov * fov + 2
+        self.obs_len = (3 if self.version == 2 else 4) * fov * fov + 2
         self.max_step = width + length
         self.timing = None
         E, n, dev = n_envs, n_agents, self.device
@@ -89,7 +90,8 @@ class VecMEDA:
             pass
 
     def get_env_info(self):
-        return {'n_actions': 9, 'n_agents': self.n_agents, 'obs_shape': (4, self.fov, self.fov, 2, self.obs_len),
+        return {'n_actions': 9, 'n_agents': self.n_agents,
+                'obs_shape': (3 if self.version == 2 else 4, self.fov, self.fov, 2, self.obs_len),
                 'episode_limit': self.max_step}
 
     def _dev(self, a, dtype):
@@ -172,6 +174,7 @@ class VecMEDA:
 
 class MEDAEnv:
     """Single-chip facade with the reference's protocol (env/MEDA/meda.py:457-681)."""
+    VERSION = 0
 
     def __init__(self, w, l, n_agents, n_blocks=0, fov=19, stall=True, b_degrade=False, per_degrade=0.1, show=False,
                  savemp4=False, seed=0, device=None):
@@ -184,7 +187,7 @@ class MEDAEnv:
         self.width, self.length, self.fov = w, l, fov
         self.max_step = w + l
         self._vec = VecMEDA(w, l, n_agents, fov=fov, b_degrade=b_degrade, per_degrade=per_degrade, n_envs=1, seed=seed,
-                            with_maps=True, device=device)
+                            with_maps=True, device=device, version=self.VERSION)
         self.rewards = {i: 0. for i in self.agents}
         self.dones = {i: False for i in self.agents}
         self.step_count = 0
@@ -198,7 +201,9 @@ class MEDAEnv:
                          lambda self, v: self._vec.set_map('degrade', np.asarray(v)))
 
     def _obs_list(self, obs):
-        o = obs[0].cpu().numpy().astype(np.float64)   # the reference returns float64 rows
+        o = obs[0].cpu().numpy()
+        if self.VERSION == 0:
+            o = o.astype(np.float64)   # the base env returns float64 rows; v0_2 returns int8 (meda.py:860)
         return [o[i].copy() for i in range(len(self.agents))]
 
     def step(self, actions):
@@ -232,7 +237,7 @@ class MEDAEnv:
         return self._obs_list(self._vec.observe())
 
     def get_env_info(self):
-        return {'n_actions': 9, 'n_agents': len(self.agents), 'obs_shape': 4 * self.fov * self.fov + 2,
+        return {'n_actions': 9, 'n_agents': len(self.agents), 'obs_shape': self._vec.obs_len,
                 'episode_limit': self.max_step}
 
     def seed(self, seed=None):
@@ -243,3 +248,8 @@ class MEDAEnv:
 
     def close(self):
         pass
+
+
+class MEDAEnv_v0_2(MEDAEnv):
+    """env/MEDA/meda.py:846-897: 3-layer int8 observation with the direction zoomed to 30x30."""
+    VERSION = 2

@@ -47,7 +47,7 @@ typedef struct {
 } meda_env;
 
 typedef struct {
-    int W, L, n, fov, b_degrade;
+    int W, L, n, fov, b_degrade, version; /* version 0: MEDAEnv.getOneObs, 2: MEDAEnv_v0_2.getOneObs */
     double per_degrade;
     int max_step;
     uint64_t seed;
@@ -134,14 +134,14 @@ int meda_oracle_check_cfg(int W, int L, int n) {
 }
 
 int meda_oracle_create(int W, int L, int n, int fov, int b_degrade, double per_degrade, int with_maps, uint64_t seed,
-                       int E, uint32_t env_id0, meda_oracle **out) {
+                       int E, uint32_t env_id0, int version, meda_oracle **out) {
     int rc = meda_oracle_check_cfg(W, L, n);
     if (rc) return rc;
     if (E <= 0 || !out || fov < 1) return MEDA_ERR_BAD_ARG;
     meda_oracle *o = (meda_oracle *)calloc(1, sizeof(*o));
     o->W = W; o->L = L; o->n = n; o->fov = fov; o->b_degrade = b_degrade; o->per_degrade = per_degrade;
     o->max_step = W + L; /* meda.py:492 */
-    o->seed = seed; o->E = E;
+    o->seed = seed; o->E = E; o->version = version;
     o->envs = (meda_env *)calloc((size_t)E, sizeof(meda_env));
     for (int k = 0; k < E; ++k) {
         meda_env *e = &o->envs[k];
@@ -372,8 +372,61 @@ static void one_obs(const meda_oracle *o, const meda_env *e, int a, signed char 
     out[4 * ff] = (signed char)(e->gx[a] - e->cx[a]);
     out[4 * ff + 1] = (signed char)(e->gy[a] - e->cy[a]);
 }
+/* MEDAEnv_v0_2.getOneObs (meda.py:850-897): 3 int8 layers + zoomed direction.  Quirks kept: the
+ * boundary layer indexes its FIRST axis with the x bound and tests x against `width` (meda.py:880-890). */
+static void one_obs_v02(const meda_oracle *o, const meda_env *e, int a, signed char *out) {
+    int fov = o->fov, ff = fov * fov, n = o->n, hf = fov / 2;
+    memset(out, 0, (size_t)(3 * ff + 2));
+    int cx = e->cx[a], cy = e->cy[a];
+    int ox = cx - hf, oy = cy - hf;
+    int observed[MEDA_MAX_AGENTS];
+    for (int j = 0; j < n; ++j) {
+        observed[j] = 0;
+        for (int y = e->cy[j] - MEDA_R; y <= e->cy[j] + MEDA_R; ++y)
+            for (int x = e->cx[j] - MEDA_R; x <= e->cx[j] + MEDA_R; ++x) {
+                int nx = x - ox, ny = y - oy;
+                if (nx >= 0 && nx < fov && ny >= 0 && ny < fov) { out[ny * fov + nx] = (signed char)(j + 1); observed[j] = 1; }
+            }
+    }
+    /* `for idx in observed` iterates a CPython set of small ints (meda.py:867-872): slot order of the
+     * hash table.  hash(i) = i; the table has 8 slots until the 5th distinct insertion, which resizes
+     * it to 32 (setobject.c: fill*5 >= mask*3 -> resize to used*4), after which slot == value, i.e.
+     * ascending order.  With at most 4 members the order is by slot (v & 7), collisions re-probed with
+     * i = (5*i + 1) & 7 (no linear probes at mask 7, perturb = v >> 5 = 0).  Later writers overwrite
+     * earlier ones where clipped goals coincide, so the order is observable. */
+    int order[MEDA_MAX_AGENTS], cnt = 0, members = 0;
+    for (int j = 0; j < n; ++j) members += observed[j];
+    if (members >= 5) {
+        for (int j = 0; j < n; ++j) if (observed[j]) order[cnt++] = j;
+    } else {
+        int slots[8];
+        for (int k = 0; k < 8; ++k) slots[k] = -1;
+        for (int j = 0; j < n; ++j)
+            if (observed[j]) { int i = j & 7; while (slots[i] >= 0) i = (i * 5 + 1) & 7; slots[i] = j; }
+        for (int k = 0; k < 8; ++k) if (slots[k] >= 0) order[cnt++] = slots[k];
+    }
+    for (int t = 0; t < cnt; ++t) {
+        int j = order[t];
+        if (j != a) put_box(out + ff, fov, e->gx[j], e->gy[j], ox, oy, j + 1, 1);
+    }
+    int left = hf - cx, right = hf - (o->W - 1 - cx);
+    if (left > 0) { for (int r = 0; r < left && r < fov; ++r) for (int c = 0; c < fov; ++c) out[2 * ff + r * fov + c] = 1; }
+    else if (right > 0) { for (int r = (fov - right < 0 ? 0 : fov - right); r < fov; ++r) for (int c = 0; c < fov; ++c) out[2 * ff + r * fov + c] = 1; }
+    int up = hf - cy, down = hf - (o->L - 1 - cy);
+    if (up > 0) { for (int r = 0; r < fov; ++r) for (int c = 0; c < up && c < fov; ++c) out[2 * ff + r * fov + c] = 1; }
+    else if (down > 0) { for (int r = 0; r < fov; ++r) for (int c = (fov - down < 0 ? 0 : fov - down); c < fov; ++c) out[2 * ff + r * fov + c] = 1; }
+    /* np.array([round(dy/(width/30)), round(dx/(length/30))], dtype=int8): python round = half to even */
+    out[3 * ff] = (signed char)(int)rint((double)(e->gy[a] - cy) / ((double)o->W / 30.0));
+    out[3 * ff + 1] = (signed char)(int)rint((double)(e->gx[a] - cx) / ((double)o->L / 30.0));
+}
+
+int meda_oracle_obs_len(const meda_oracle *o) { return (o->version == 2 ? 3 : 4) * o->fov * o->fov + 2; }
+
 void meda_oracle_observe(const meda_oracle *o, signed char *obs) {
-    int len = 4 * o->fov * o->fov + 2;
+    int len = meda_oracle_obs_len(o);
     for (int k = 0; k < o->E; ++k)
-        for (int i = 0; i < o->n; ++i) one_obs(o, &o->envs[k], i, obs + ((size_t)k * o->n + i) * len);
+        for (int i = 0; i < o->n; ++i) {
+            if (o->version == 2) one_obs_v02(o, &o->envs[k], i, obs + ((size_t)k * o->n + i) * len);
+            else one_obs(o, &o->envs[k], i, obs + ((size_t)k * o->n + i) * len);
+        }
 }

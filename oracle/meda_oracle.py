@@ -25,7 +25,7 @@ def lib():
             subprocess.check_call(['make', '-C', _HERE, '-s'])
         L = C.CDLL(so)
         vp, i32, u32, u64, f64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_double
-        L.meda_oracle_create.argtypes = [i32, i32, i32, i32, i32, f64, i32, u64, i32, u32, C.POINTER(vp)]
+        L.meda_oracle_create.argtypes = [i32, i32, i32, i32, i32, f64, i32, u64, i32, u32, i32, C.POINTER(vp)]
         L.meda_oracle_check_cfg.argtypes = [i32, i32, i32]
         for name, args in [('destroy', [vp]), ('reset', [vp, vp]), ('restart', [vp, vp]), ('set_task', [vp, vp, vp]),
                            ('get_task', [vp, vp, vp]), ('get_state', [vp, vp, vp, vp, vp]),
@@ -53,13 +53,13 @@ class MedaOracle:
     MAP = {'health': 0, 'usage': 1, 'degrade': 2}
 
     def __init__(self, width, length, n_agents, fov=19, b_degrade=False, per_degrade=0.1, n_envs=1, seed=0,
-                 with_maps=False, env_id0=0):
+                 with_maps=False, env_id0=0, version=0):
         self.W, self.L, self.n, self.fov, self.E = width, length, n_agents, fov, n_envs
         self.h = C.c_void_p()
         _check(lib().meda_oracle_create(width, length, n_agents, fov, int(b_degrade), float(per_degrade),
-                                        int(with_maps), seed, n_envs, env_id0, C.byref(self.h)))
+                                        int(with_maps), seed, n_envs, env_id0, int(version), C.byref(self.h)))
         self.max_step = width + length
-        self.obs_len = 4 * fov * fov + 2
+        self.obs_len = (3 if version == 2 else 4) * fov * fov + 2
 
     def __del__(self):
         if getattr(self, 'h', None) is not None and self.h:

@@ -30,10 +30,11 @@ def _compare(B, g, idx, active, t):
 
 
 def replay_independent(g, make_backend):
-    W, L, n, fov, has_health, chain = [int(v) for v in g['cfg']]
+    W, L, n, fov, has_health, chain = [int(v) for v in g['cfg'][:6]]
+    version = int(g['cfg'][6]) if len(g['cfg']) > 6 else 0
     ep_len = g['ep_len'].astype(int)
     E = len(ep_len)
-    B = make_backend(width=W, length=L, n_agents=n, fov=fov, n_envs=E, with_maps=bool(has_health))
+    B = make_backend(width=W, length=L, n_agents=n, fov=fov, n_envs=E, with_maps=bool(has_health), version=version)
     if has_health:
         B.set_map('health', g['health'])
     B.set_task(g['starts'], g['ends'])
@@ -53,7 +54,7 @@ def replay_independent(g, make_backend):
 
 
 def replay_chain(g, make_backend):
-    W, L, n, fov, has_health, chain = [int(v) for v in g['cfg']]
+    W, L, n, fov, has_health, chain = [int(v) for v in g['cfg'][:6]]
     B = make_backend(width=W, length=L, n_agents=n, fov=fov, n_envs=1, b_degrade=True, per_degrade=1.0)
     B.set_map('degrade', g['degrade'][None])
     B.set_map('usage', g['usage_init'][None])

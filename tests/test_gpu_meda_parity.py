@@ -125,3 +125,32 @@ def test_full_size_invariants_4096():
         assert bool((o[:, :, (fov // 2) * fov + fov // 2] == idx).all())      # own footprint centre in layer 0
         assert bool((o[:, :, :ff].ne(0).sum(-1) == 25).all())                 # whole 5x5 footprint is visible
         assert bool((info['constraints'] <= 0).all())
+
+
+def test_lockstep_v0_2_observation():
+    """MEDAEnv_v0_2.getOneObs (meda.py:850-897), incl. the CPython-set iteration order of layer 1."""
+    _lockstep(dict(C30, version=2), E=300, steps=120, seed=20, autoreset=True)
+    _lockstep(dict(width=60, length=75, n_agents=12, fov=19, version=2), E=64, steps=140, seed=21, autoreset=True, greedy=0.9)
+    _lockstep(dict(width=30, length=60, n_agents=8, fov=9, version=2), E=50, steps=90, seed=22, autoreset=False)
+
+
+def test_meda_v0_2_trains_with_crnn():
+    """with the v0_2 observation (3 int8 layers, fov 19 -> the tied-weight conv stack of
+    network/base_net.py:25-32) the MEDA env drives the same RolloutWorker / ReplayBuffer / VDN.learn loop
+    (the reference's own MEDA training path is broken: get_env_info returns an int, meda.py:676-681)."""
+    from marl_dmfb_amd.common.arguments import make_args
+    from marl_dmfb_amd.env.meda import VecMEDA
+    from marl_dmfb_amd.train import Trainer
+    env = VecMEDA(30, 30, 4, fov=19, n_envs=64, seed=3, version=2)
+    args = make_args(name='meda', drop_num=4, width=30, length=30, fov=19, device='cuda:0', n_envs=64, batch_size=32,
+                     buffer_size=256, **env.get_env_info())
+    torch.manual_seed(0)
+    tr = Trainer(env, args)
+    assert list(tr.agents.policy.eval_rnn.state_dict().keys())[:6] == [
+        'conv1.weight', 'conv1.bias', 'conv2.weight', 'conv2.bias', 'conv3.weight', 'conv3.bias']
+    assert tr.agents.policy.eval_rnn.conv2.weight is tr.agents.policy.eval_rnn.conv3.weight      # tied, as in the reference
+    w0 = tr.agents.policy.eval_rnn.fc1.weight.detach().clone()
+    played = tr.collect_and_learn()
+    assert played > 64 and tr.trained_times == args.train_time
+    assert torch.isfinite(tr.agents.policy.last_loss)
+    assert not torch.equal(w0, tr.agents.policy.eval_rnn.fc1.weight)

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ref_shim  # noqa: E402
 
 ref_shim.install()
-from env.MEDA.meda import MEDAEnv, Droplet  # noqa: E402
+from env.MEDA.meda import MEDAEnv, MEDAEnv_v0_2, Droplet  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 'tests', 'golden')
 QUEUE = ref_shim.DrawQueue()
@@ -102,10 +102,10 @@ def run_episode(rng, env, rec, greedy, exact_prob):
     return steps
 
 
-def gen(name, W, L, n, fov, n_episodes, seed, with_health=False, degrade_chain=False):
+def gen(name, W, L, n, fov, n_episodes, seed, with_health=False, degrade_chain=False, version=0):
     rng = np.random.default_rng(seed)
     np.random.seed(seed)
-    env = MEDAEnv(W, L, n, fov=fov, b_degrade=degrade_chain, per_degrade=1.0)
+    env = (MEDAEnv_v0_2 if version == 2 else MEDAEnv)(W, L, n, fov=fov, b_degrade=degrade_chain, per_degrade=1.0)
     rec = {k: [] for k in ['actions', 'uniforms', 'rewards', 'dones', 'fail', 'success', 'obs', 'pos', 'status']}
     ep = {k: [] for k in ['starts', 'ends', 'ep_len', 'obs0', 'health', 'usage', 'usage_end']}
     if degrade_chain:
@@ -137,7 +137,7 @@ def gen(name, W, L, n, fov, n_episodes, seed, with_health=False, degrade_chain=F
     out = {k: np.stack(v) for k, v in rec.items()}
     out.update({k: np.stack(v) for k, v in ep.items()})
     out.update(extra)
-    out['cfg'] = np.array([W, L, n, fov, int(with_health or degrade_chain), int(degrade_chain)], np.int32)
+    out['cfg'] = np.array([W, L, n, fov, int(with_health or degrade_chain), int(degrade_chain), version], np.int32)
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, 'meda_%s.npz' % name)
     np.savez_compressed(path, **out)
@@ -147,6 +147,12 @@ def gen(name, W, L, n, fov, n_episodes, seed, with_health=False, degrade_chain=F
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'v02':
+        gen('v02_30x30_4d_fov19', 30, 30, 4, 19, n_episodes=16, seed=21, version=2)
+        gen('v02_30x60_4d_fov19', 30, 60, 4, 19, n_episodes=12, seed=22, version=2)
+        gen('v02_80x80_10d_fov19', 80, 80, 10, 19, n_episodes=5, seed=23, version=2)
+        gen('v02_60x75_12d_fov19', 60, 75, 12, 19, n_episodes=4, seed=24, version=2)
+        sys.exit(0)
     gen('30x30_4d_fov19', 30, 30, 4, 19, n_episodes=40, seed=11)
     gen('30x60_4d_fov19_health', 30, 60, 4, 19, n_episodes=24, seed=12, with_health=True)
     gen('30x60_8d_fov19', 30, 60, 8, 19, n_episodes=10, seed=13)
