@@ -261,13 +261,14 @@ def main():
         except Exception:
             traffic = None
     out = {
-        'metric': 'env-steps/sec (whole node), 10x10 DMFB 4-droplet fov9',
+        'metric': 'env-steps/sec (whole node), %dx%d DMFB %d-droplet fov%d' % (a.width, a.length, a.drop_num, a.fov),
         'value': round(played_all / dt_max, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': round(dt_max / a.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8 env state/obs + f64 rewards; fp32 Q-net',
         'data': 'synthetic (Philox task generator, random-init CRNN)',
-        'config': {'workload': 'DMFB %dx%d, drop_num=%d, fov=%d, %d parallel envs per GPU (BASELINE configs[1])' % (
-            a.width, a.length, a.drop_num, a.fov, a.n_envs),
+        'config': {'workload': 'DMFB %dx%d, drop_num=%d, fov=%d, %d parallel envs per GPU%s' % (
+            a.width, a.length, a.drop_num, a.fov, a.n_envs,
+            ' (BASELINE configs[1])' if (a.width, a.length, a.drop_num, a.fov, a.n_envs) == (10, 10, 4, 9, 4096) else ''),
             'round': 'one episode per chip (<=%d lock-steps) + %d learns x %d episodes' % (
                 env.max_step, a.train_time, a.batch_size),
             'parallelism': 'dp%d: chips sharded per rank, one flat RCCL all-reduce per learn' % world,

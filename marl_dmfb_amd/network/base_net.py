@@ -44,6 +44,45 @@ class _ConvGemm(torch.autograd.Function):
         return gcols, gw, g.sum(0)
 
 
+class _GRUSeq(torch.autograd.Function):
+    """GRU cell unrolled over a whole sequence as ONE autograd node (GPU only).
+
+    forward: per step `h @ W_hh^T` + the fused gate kernel (`_thnn_fused_gru_cell`, what nn.GRUCell
+    dispatches to).  backward: per step the fused gate backward + one small GEMM for the hidden
+    gradient; the weight gradient of W_hh and both bias gradients are formed ONCE from the stacked
+    gate gradients instead of T accumulations of tiny per-step results."""
+
+    @staticmethod
+    def forward(ctx, igates, h0, w_hh, b_ih, b_hh):
+        T = igates.shape[0]
+        w_hh_t = w_hh.t()
+        h, hs, wss = h0, [], []
+        for t in range(T):
+            h, ws = torch.ops.aten._thnn_fused_gru_cell(igates[t], torch.matmul(h, w_hh_t), h, b_ih, b_hh)
+            hs.append(h)
+            wss.append(ws)
+        out = torch.stack(hs, dim=0)
+        ctx.save_for_backward(out, h0, w_hh, *wss)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        out, h0, w_hh, *wss = ctx.saved_tensors
+        T, R, H = out.shape
+        d_ig = torch.empty((T, R, 3 * H), dtype=out.dtype, device=out.device)
+        d_hg = torch.empty_like(d_ig)
+        gh = None
+        for t in range(T - 1, -1, -1):
+            g = grad_out[t] if gh is None else grad_out[t] + gh
+            gi, ghg, ghx, _, _ = torch.ops.aten._thnn_fused_gru_cell_backward(g.contiguous(), wss[t], False)
+            d_ig[t] = gi
+            d_hg[t] = ghg
+            gh = torch.addmm(ghx, ghg, w_hh)
+        h_prev = torch.cat([h0.unsqueeze(0), out[:-1]], dim=0)
+        d_w_hh = torch.matmul(d_hg.view(T * R, 3 * H).t(), h_prev.view(T * R, H))
+        return d_ig, gh, d_w_hh, d_ig.sum(dim=(0, 1)), d_hg.sum(dim=(0, 1))
+
+
 def conv_str(fov, id=3, od=32):
     stack, shared = [], None
     for from_image, stride in _CONV_PLAN[fov]:
@@ -123,10 +162,9 @@ class CRNN(nn.Module):
         hs = []
         if x_seq.is_cuda:
             igates = torch.matmul(x_seq.reshape(T * R, -1), self.rnn.weight_ih.t()).view(T, R, -1)
-            w_hh_t = self.rnn.weight_hh.t()
-            for t in range(T):
-                h = torch.ops.aten._thnn_fused_gru_cell(igates[t], torch.matmul(h, w_hh_t), h, self.rnn.bias_ih, self.rnn.bias_hh)[0]
-                hs.append(h)
+            hseq = _GRUSeq.apply(igates, h, self.rnn.weight_hh, self.rnn.bias_ih, self.rnn.bias_hh)
+            q = self.fc1(hseq.view(T * R, -1)).view(T, R, -1)
+            return q, hseq[-1]
         else:
             for t in range(T):
                 h = self.rnn(x_seq[t], h)

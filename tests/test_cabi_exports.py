@@ -77,3 +77,15 @@ def test_meda_check_config_codes():
     assert lib.meda_vec_check_config(C.byref(cfg(n_agents=5))) == -3
     assert lib.meda_vec_check_config(C.byref(cfg(n_agents=0))) == -5
     assert lib.meda_vec_check_config(C.byref(cfg(width=0))) == -4
+
+
+def test_crnn_ops_library_exports():
+    lib = _lib.crnn_ops()
+    txt = open(os.path.join(ROOT, 'include', 'crnn_ops.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    names = sorted(set(re.findall(r'\b(crnn_[a-z_0-9]+)\s*\(', txt)))
+    assert names == ['crnn_conv9_forward', 'crnn_last_hip_error']
+    for n in names:
+        assert hasattr(lib, n)
+    # argument guards run on the host before anything touches the GPU
+    assert lib.crnn_conv9_forward(None, 245, 4, None, None, None, None, 24, None, 600, None) == -1
