@@ -81,7 +81,7 @@ class Evaluator:
         alive = torch.ones(E, dtype=torch.bool, device=dev)
         reward = torch.zeros(E, dtype=torch.float64, device=dev)
         steps = torch.zeros(E, dtype=torch.int64, device=dev)
-        constraints = torch.zeros(E, dtype=torch.int64, device=dev)
+        constraints = torch.zeros(E, dtype=torch.float64, device=dev)  # MEDA reports a float (sum of punishments)
         success = torch.zeros(E, dtype=torch.int64, device=dev)
         ep = None
         if record:
@@ -101,30 +101,35 @@ class Evaluator:
                                                          generator=self.generator)
             onehot = torch.nn.functional.one_hot(actions, A).to(torch.int8)
             if record:
-                ep['o'][:, t] = torch.where(alive[:, None, None], obs, torch.zeros_like(obs))
+                ep['o'][:, t] = obs  # rows of frozen chips are zeroed in one pass after the loop
+            # frozen chips are not stepped: the kernel reports reward 0 / constraints 0 / success 0 / terminated 1
             obs, _, _, info = self.env.step(actions, active=alive, record=True)
             term = info['terminated'].bool()
-            live = alive
             if record:
-                m3 = live[:, None, None]
-                ep['u'][:, t] = torch.where(m3, actions.unsqueeze(-1).to(torch.int8), 0)
-                ep['r'][:, t, 0] = torch.where(live, info['team_reward'].float(), 0.0)
-                ep['o_next'][:, t] = torch.where(m3, obs, torch.zeros_like(obs))
-                ep['u_onehot'][:, t] = torch.where(m3, onehot, 0)
-                ep['avail_u'][:, t] = m3.to(torch.int8).expand(E, n, A)
-                ep['avail_u_next'][:, t] = m3.to(torch.int8).expand(E, n, A)
-                ep['padded'][:, t, 0] = ~live
-                ep['terminated'][:, t, 0] = term | ~live
-            reward += torch.where(live, info['team_reward'], 0.0)
-            constraints += torch.where(live, info['constraints'].long(), 0)
-            success += torch.where(live, info['success'].long(), 0)
-            steps += live.long()
+                ep['u'][:, t, :, 0] = actions
+                ep['r'][:, t, 0] = info['team_reward']
+                ep['o_next'][:, t] = obs
+                ep['u_onehot'][:, t] = onehot
+                ep['padded'][:, t, 0] = ~alive
+                ep['terminated'][:, t, 0] = term
+            reward += info['team_reward']
+            constraints += info['constraints']
+            success += info['success']
+            steps += alive
             if not evaluate and self.agents.args.epsilon_anneal_scale == 'step':
-                eps = torch.clamp(eps - self.anneal_epsilon * live.sum(), min=self.min_epsilon)
+                eps = torch.clamp(eps - self.anneal_epsilon * alive.sum(), min=self.min_epsilon)
             last_action = onehot
             alive = alive & ~term
             if not self._capturing and (t + 1) % self.sync_every == 0 and not bool(alive.any()):
                 break
+        if record:  # padding rules of rollout.py:131-141 applied once: zeros, avail 0 where padded
+            valid = ~ep['padded']                                   # (E, T, 1)
+            v4 = valid.unsqueeze(-1)
+            for key in ('o', 'o_next', 'u', 'u_onehot'):
+                ep[key] *= v4
+            ep['r'] *= valid
+            ep['avail_u'][:] = v4
+            ep['avail_u_next'][:] = v4
         steps = torch.where(success > 0, steps, torch.full_like(steps, self.episode_limit))
         return reward, steps, constraints, success, ep, eps
 
