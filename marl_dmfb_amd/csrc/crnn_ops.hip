@@ -7,7 +7,8 @@
 // blocks of RB rows through conv1 (LDS -> registers -> LDS) and conv2 (LDS -> registers -> HBM):
 //   thread (row r, channel c) owns one output channel of one row; per input channel it pulls the
 //   7x7 conv1 activations of row r into registers with 16-byte LDS reads (the same address for all
-//   channels of a row = broadcast) and applies its 9 weights: 225 FMAs per 58 LDS words.
+//   channels of a row = broadcast) and applies its 9 weights: 225 FMAs per 58 LDS words.  conv2
+//   weights sit in LDS as (c1, tap, c2) so the 24/32 channel lanes of a row hit consecutive banks.
 // fp32 VALU FMAs (v_fma_f32), no MFMA: the fp32 MFMA rate equals the VALU rate on gfx950 and the
 // tiles (24 x 25) are far below an MFMA-friendly shape.
 #include <hip/hip_runtime.h>
@@ -37,14 +38,17 @@ __global__ __launch_bounds__(kBlock) void k_conv9(const int8_t *__restrict__ obs
                                                   float *__restrict__ out, long out_stride) {
     using G = Geo<OD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *s_w2 = lds;                         // [OD][OD][9]  (c2, c1, tap)
+    float *s_w2 = lds;                         // [OD c1][9 tap][OD c2]: lanes (= c2) read consecutive banks
     float *s_w1 = s_w2 + OD * OD * 9;          // [OD][27]
     float *s_b1 = s_w1 + OD * 27;              // [OD]
     float *s_b2 = s_b1 + OD;                   // [OD]
     float *s_in = s_b2 + OD;                   // [RB][244]
     float *s_a1 = s_in + G::RB * G::IN_STRIDE; // [RB][ROW_A1], 16-byte aligned by construction
     const int tid = threadIdx.x;
-    for (int i = tid; i < OD * OD * 9; i += kBlock) s_w2[i] = w2[i];
+    for (int i = tid; i < OD * OD * 9; i += kBlock) {  // global (c2, c1, tap) -> LDS (c1, tap, c2)
+        const int c2 = i / (OD * 9), rem = i - c2 * OD * 9;
+        s_w2[rem * OD + c2] = w2[i];
+    }
     for (int i = tid; i < OD * 27; i += kBlock) s_w1[i] = w1[i];
     if (tid < OD) { s_b1[tid] = b1[tid]; s_b2[tid] = b2[tid]; }
     const int r = tid / OD, c = tid - r * OD;  // row in block, output channel
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9(const int8_t *__restrict__ obs
 #pragma unroll
             for (int k = 0; k < 25; ++k) acc[k] = bias;
             const float *a1row = s_a1 + r * G::ROW_A1;
-            const float *wrow = s_w2 + c * OD * 9;
+            const float *wrow = s_w2 + c;
 #pragma unroll 2
             for (int c1 = 0; c1 < OD; ++c1) {
                 float a[kA1Stride];
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9(const int8_t *__restrict__ obs
                 }
                 float w[9];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) w[k] = wrow[c1 * 9 + k];
+                for (int k = 0; k < 9; ++k) w[k] = wrow[(c1 * 9 + k) * OD];
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
