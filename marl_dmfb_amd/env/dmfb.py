@@ -246,6 +246,16 @@ class _RoutingManagerView:
     def distances(self):
         return self._env._vec.get_state()['dist'][0].cpu().numpy().astype(int)
 
+    @property
+    def blocks(self):
+        """(x_min, x_max, y_min, y_max) per block, like the reference's Block objects (dmfb.py:34-41)."""
+        return [tuple(int(v) for v in b) for b in self._env._vec.get_blocks()[0].cpu().numpy()]
+
+    @blocks.setter
+    def blocks(self, value):
+        rows = [(b.x_min, b.x_max, b.y_min, b.y_max) if hasattr(b, 'x_min') else tuple(b) for b in value]
+        self._env._vec.set_blocks(np.asarray(rows, np.int32).reshape(1, -1, 4))
+
     def set_task(self, starts, ends):
         """starts/ends assignment + restartforall (dmfb.py:185-190)."""
         self._env._vec.set_task(np.asarray(starts)[None], np.asarray(ends)[None])
