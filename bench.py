@@ -179,13 +179,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = world > 1
+    # BENCH_FORCE_DIST=1 runs the collective path (RCCL init, broadcast, all-reduce) even with one rank
+    force_dist = bool(os.environ.get('BENCH_FORCE_DIST'))
+    dist = world > 1 or force_dist
     # BENCH_DIST_BACKEND=gloo rehearses the multi-rank control flow with all ranks on one GPU
     backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if dist:
+        if force_dist and 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         if backend == 'nccl':
             torch.distributed.init_process_group('nccl', device_id=device)
         else:
@@ -199,7 +203,7 @@ def main():
     env = VecDMFB(n_envs=a.n_envs, seed=1234, env_id0=rank * a.n_envs, device=device, **cfg)
     args = make_args(drop_num=a.drop_num, width=a.width, length=a.length, fov=a.fov, device=str(device), dist=dist,
                      n_envs=a.n_envs, batch_size=a.batch_size, train_time=a.train_time, buffer_size=a.buffer_size,
-                     use_graph=a.graph,
+                     use_graph=a.graph, force_dist=force_dist,
                      **env.get_env_info())
     torch.manual_seed(1234 + rank)
     trainer = Trainer(env, args)

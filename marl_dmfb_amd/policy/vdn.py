@@ -88,7 +88,8 @@ class VDN:
         self.last_grad_norm = None
         self._flat = None
         self.dist = bool(getattr(args, 'dist', False)) and torch.distributed.is_available() \
-            and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+            and torch.distributed.is_initialized() \
+            and (torch.distributed.get_world_size() > 1 or bool(getattr(args, 'force_dist', False)))
         if self.dist:
             self.broadcast_parameters()
 
