@@ -4,7 +4,7 @@
 // Why a kernel: in the rollout the network sees (envs x agents) = 16 384 rows of 3x9x9 int8 pixels
 // per lock-step.  Through library GEMMs this is two im2col copies plus two GEMMs with N = 24 output
 // columns (17 TFLOP/s, ~0.55 ms).  Here one workgroup keeps both weight tensors in LDS and pushes
-// blocks of RB rows through conv1 (LDS -> registers -> LDS) and conv2 (LDS -> registers -> HBM):
+// blocks of RB rows (21 for od 24) through conv1 (LDS -> registers -> LDS) and conv2 (LDS -> registers -> HBM):
 //   thread (row r, channel c) owns one output channel of one row; per input channel it pulls the
 //   7x7 conv1 activations of row r into registers with 16-byte LDS reads (the same address for all
 //   channels of a row = broadcast) and applies its 9 weights: 225 FMAs per 58 LDS words.  conv2
@@ -21,11 +21,16 @@
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 512;  // 8 waves: one workgroup per CU keeps ONE copy of the weights in LDS for 2 waves per SIMD
 constexpr int kA1Stride = 52;  // 49 conv1 activations per (row, channel), padded to a 16-byte multiple
 
+constexpr int kLdsBudget = 158 * 1024;  // of the CU's 160 KiB
+
 template <int OD> struct Geo {
-    static constexpr int RB = kBlock / OD;              // rows per block iteration (24 -> 10, 32 -> 8)
+    static constexpr int ROW_BYTES = (OD * kA1Stride + 4 + 244) * 4;               // a1 row + input row
+    static constexpr int FIXED_BYTES = (OD * OD * 9 + OD * 27 + 2 * OD) * 4;       // weights + biases
+    static constexpr int RB_LDS = (kLdsBudget - FIXED_BYTES) / ROW_BYTES;
+    static constexpr int RB = (kBlock / OD) < RB_LDS ? (kBlock / OD) : RB_LDS;      // rows per iteration (24 -> 21, 32 -> 15)
     static constexpr int ROW_A1 = OD * kA1Stride + 4;   // +4 floats: rows start on different banks
     static constexpr int IN_STRIDE = 244;               // 243 pixels (+1)
     static constexpr size_t LDS_FLOATS = (size_t)OD * OD * 9 + OD * 27 + 2 * OD + (size_t)RB * IN_STRIDE + (size_t)RB * ROW_A1;
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9(const int8_t *__restrict__ obs
 #pragma unroll 2
             for (int c1 = 0; c1 < OD; ++c1) {
                 float a[kA1Stride];
-                const float4 *src = (const float4 *)(a1row + c1 * kA1Stride);
+                const float4 *src = (const float4 *)__builtin_assume_aligned(a1row + c1 * kA1Stride, 16);  // ds_read_b128
 #pragma unroll
                 for (int q = 0; q < kA1Stride / 4; ++q) {
                     const float4 t = src[q];
@@ -144,7 +149,7 @@ int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const
         attr_set = true;
     }
     const long n_blocks = (rows + G::RB - 1) / G::RB;
-    const int grid = (int)(n_blocks < 512 ? n_blocks : 512);  // persistent: 2 workgroups per CU keep the weights resident
+    const int grid = (int)(n_blocks < 256 ? n_blocks : 256);  // persistent: one 8-wave workgroup per CU keeps the weights resident
     (void)hipGetLastError();
     hipLaunchKernelGGL((k_conv9<OD>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, w1, b1, w2, b2, out, out_stride);
     hipError_t e = hipGetLastError();
