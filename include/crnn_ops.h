@@ -28,6 +28,16 @@ extern "C" {
  * d_out:  float32 [rows][out_stride], first od*25 entries of a row are written, index c*25 + h*5 + w */
 int crnn_conv9_forward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_w1, const float *d_b1,
                        const float *d_w2, const float *d_b2, int od, float *d_out, int64_t out_stride, void *stream);
+/* The whole non-recurrent front end of CRNN.forward (network/base_net.py:59-68) for fov 9: the pixel
+ * block as above AND the vector branch relu(mlp1([dir(2), last_action_onehot(n_actions)])), written
+ * side by side so that a row of d_out IS the GRU input `x = cat([pixel, vec], dim=1)`:
+ *   d_out[r][0 .. od*25)            conv features
+ *   d_out[r][od*25 .. od*25+10)     relu(mlp1(vec)),  vec = [obs[r][243], obs[r][244], onehot[r][0..n_actions)]
+ * d_onehot: int8 [rows][n_actions] (may be NULL = all zeros: first step of an episode);
+ * d_mlp_w: float32 [10][2+n_actions] (mlp1.weight), d_mlp_b: [10]; n_actions <= 16. */
+int crnn_front9_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
+                        const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
+                        const float *d_mlp_b, int od, float *d_out, int64_t out_stride, void *stream);
 int crnn_last_hip_error(void);
 
 #ifdef __cplusplus

@@ -40,7 +40,9 @@ template <int OD>
 __global__ __launch_bounds__(kBlock) void k_conv9(const int8_t *__restrict__ obs, long obs_stride, long rows,
                                                   const float *__restrict__ w1, const float *__restrict__ b1,
                                                   const float *__restrict__ w2, const float *__restrict__ b2,
-                                                  float *__restrict__ out, long out_stride) {
+                                                  float *__restrict__ out, long out_stride,
+                                                  const int8_t *__restrict__ onehot, int n_actions,
+                                                  const float *__restrict__ mlp_w, const float *__restrict__ mlp_b) {
     using G = Geo<OD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *s_w2 = lds;                         // [OD c1][9 tap][OD c2]: lanes (= c2) read consecutive banks
@@ -131,6 +133,16 @@ __global__ __launch_bounds__(kBlock) void k_conv9(const int8_t *__restrict__ obs
             float *o = out + (row0 + r) * out_stride + c * 25;
 #pragma unroll
             for (int k = 0; k < 25; ++k) o[k] = fmaxf(acc[k], 0.0f);
+            if (mlp_w && c < 10) {  // vector branch: relu(mlp1([dir_x, dir_y, last-action one-hot])) (base_net.py:66)
+                const int nin = 2 + n_actions;
+                const int8_t *ob = obs + (row0 + r) * obs_stride;
+                float v = mlp_b[c];
+                v = fmaf((float)ob[243], mlp_w[c * nin], v);
+                v = fmaf((float)ob[244], mlp_w[c * nin + 1], v);
+                if (onehot)
+                    for (int k = 0; k < n_actions; ++k) v = fmaf((float)onehot[(row0 + r) * n_actions + k], mlp_w[c * nin + 2 + k], v);
+                out[(row0 + r) * out_stride + OD * 25 + c] = fmaxf(v, 0.0f);
+            }
         }
     }
 }
@@ -139,7 +151,8 @@ thread_local int g_last_hip = 0;
 
 template <int OD>
 int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w2,
-           const float *b2, float *out, long out_stride, hipStream_t s) {
+           const float *b2, float *out, long out_stride, const int8_t *onehot, int n_actions, const float *mlp_w,
+           const float *mlp_b, hipStream_t s) {
     using G = Geo<OD>;
     const size_t lds = G::LDS_FLOATS * sizeof(float);
     static bool attr_set = false;
@@ -151,7 +164,8 @@ int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const
     const long n_blocks = (rows + G::RB - 1) / G::RB;
     const int grid = (int)(n_blocks < 256 ? n_blocks : 256);  // persistent: one 8-wave workgroup per CU keeps the weights resident
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_conv9<OD>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, w1, b1, w2, b2, out, out_stride);
+    hipLaunchKernelGGL((k_conv9<OD>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, w1, b1, w2, b2, out, out_stride, onehot,
+                       n_actions, mlp_w, mlp_b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_last_hip = (int)e;
@@ -170,8 +184,20 @@ int crnn_conv9_forward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, co
     if (!d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_out || rows < 0 || obs_stride < 243 || out_stride < od * 25)
         return CRNN_ERR_BAD_ARG;
     if (rows == 0) return CRNN_OK;
-    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, (hipStream_t)stream);
-    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, (hipStream_t)stream);
+    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+    return CRNN_ERR_UNSUPPORTED;
+}
+
+int crnn_front9_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
+                        const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
+                        const float *d_mlp_b, int od, float *d_out, int64_t out_stride, void *stream) {
+    if (!d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_mlp_w || !d_mlp_b || !d_out || rows < 0 || obs_stride < 245 ||
+        out_stride < od * 25 + 10 || n_actions < 0 || n_actions > 16)
+        return CRNN_ERR_BAD_ARG;
+    if (rows == 0) return CRNN_OK;
+    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
+    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
 }
 

@@ -195,6 +195,30 @@ class CRNN(nn.Module):
             raise RuntimeError('crnn_conv9_forward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
         return out
 
+    def _front_features_hip(self, obs_i8, onehot_i8):
+        """GRU input x = cat([conv features, relu(mlp1([dir, last action]))]) in one HIP launch
+        (include/crnn_ops.h: crnn_front9_forward); inference only."""
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.crnn_ops()
+        obs_i8 = obs_i8.contiguous()
+        R = obs_i8.shape[0]
+        out = torch.empty((R, self.out + 10), dtype=torch.float32, device=obs_i8.device)
+        c1, c2 = self.convs[0], self.convs[1]
+        oh = None
+        if onehot_i8 is not None:
+            onehot_i8 = onehot_i8.to(torch.int8).contiguous()
+            oh = C.c_void_p(onehot_i8.data_ptr())
+        rc = lib.crnn_front9_forward(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), oh, self.n_actions, R,
+                                     C.c_void_p(c1.weight.data_ptr()), C.c_void_p(c1.bias.data_ptr()),
+                                     C.c_void_p(c2.weight.data_ptr()), C.c_void_p(c2.bias.data_ptr()),
+                                     C.c_void_p(self.mlp1.weight.data_ptr()), C.c_void_p(self.mlp1.bias.data_ptr()),
+                                     c1.out_channels, C.c_void_p(out.data_ptr()), out.stride(0),
+                                     C.c_void_p(torch.cuda.current_stream(obs_i8.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('crnn_front9_forward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
+        return out
+
     def _hip_conv_ok(self, obs_i8):
         return (self.conv_impl == 'gemm' and obs_i8.is_cuda and obs_i8.dtype == torch.int8 and not torch.is_grad_enabled()
                 and self.input_dim[:3] == (3, 9, 9) and len(self.convs) == 2 and self.convs[0].out_channels in (24, 32)
@@ -202,11 +226,8 @@ class CRNN(nn.Module):
 
     def forward_obs(self, obs_i8, last_action_onehot, hidden_state):
         """obs_i8 (R, 3*fov*fov+2) int8 as written by the env kernels; last_action_onehot (R, n_actions)."""
-        if self._hip_conv_ok(obs_i8):
-            pix = self._pixel_features_hip(obs_i8)
-            vec = torch.cat([obs_i8[:, self.n_pixel:].float(), last_action_onehot.float()], dim=1)
-            x = torch.cat([pix, f.relu(self.mlp1(vec))], dim=1)
-            return self.recurrent(x, hidden_state)
+        if self._hip_conv_ok(obs_i8) and self.mlp1.in_features == 2 + self.n_actions and self.n_actions <= 16:
+            return self.recurrent(self._front_features_hip(obs_i8, last_action_onehot), hidden_state)
         pixel = obs_i8[:, :self.n_pixel].float()
         vec = torch.cat([obs_i8[:, self.n_pixel:].float(), last_action_onehot.float()], dim=1)
         return self.recurrent(self.features_split(pixel, vec), hidden_state)

@@ -196,9 +196,7 @@ class VDN:
     def _features(self, net, obs_rows, la_rows):
         if la_rows is not None and hasattr(net, '_hip_conv_ok') and net._hip_conv_ok(obs_rows):
             # no-grad pass (target net) over int8 rows: hand-written HIP conv front end
-            pix = net._pixel_features_hip(obs_rows)
-            vec = torch.cat([obs_rows[:, net.n_pixel:].float(), la_rows], dim=1)
-            return torch.cat([pix, torch.relu(net.mlp1(vec))], dim=1)
+            return net._front_features_hip(obs_rows, la_rows)
         x = obs_rows.float()
         if la_rows is not None:
             x = torch.cat([x, la_rows], dim=1)
