@@ -42,7 +42,8 @@ __global__ __launch_bounds__(kBlock) void k_conv9(const int8_t *__restrict__ obs
                                                   const float *__restrict__ w2, const float *__restrict__ b2,
                                                   float *__restrict__ out, long out_stride,
                                                   const int8_t *__restrict__ onehot, int n_actions,
-                                                  const float *__restrict__ mlp_w, const float *__restrict__ mlp_b) {
+                                                  const float *__restrict__ mlp_w, const float *__restrict__ mlp_b,
+                                                  float *__restrict__ a1_save) {
     using G = Geo<OD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *s_w2 = lds;                         // [OD c1][9 tap][OD c2]: lanes (= c2) read consecutive banks
@@ -97,6 +98,11 @@ __global__ __launch_bounds__(kBlock) void k_conv9(const int8_t *__restrict__ obs
                     }
 #pragma unroll
                 for (int y = 0; y < 7; ++y) a1[x * 7 + y] = fmaxf(acc[y], 0.0f);
+                if (a1_save) {  // training: keep the conv1 activations for the backward kernel
+                    float *sv = a1_save + ((row0 + r) * OD + c) * 49 + x * 7;
+#pragma unroll
+                    for (int y = 0; y < 7; ++y) sv[y] = fmaxf(acc[y], 0.0f);
+                }
             }
         }
         __syncthreads();
@@ -147,12 +153,186 @@ __global__ __launch_bounds__(kBlock) void k_conv9(const int8_t *__restrict__ obs
     }
 }
 
+
+// ---- backward of conv1+ReLU+conv2+ReLU w.r.t. the four parameter tensors (the int8 observation needs no
+// gradient).  One persistent 512-thread workgroup per CU walks blocks of RBB rows; every thread keeps
+// its share of the weight-gradient sums in registers over ALL the rows of the workgroup and writes
+// them once to part[blockIdx][...]; the host adds the <= 256 partial vectors (deterministic, no atomics).
+//   P0  stage a1 (saved by the forward), dz2 = g * (a2 > 0) and the float input rows in LDS
+//   P1  dW2[c2][c1][tap] += sum_pos dz2[c2][pos] * a1[c1][pos + tap]         thread = (c2, c1) pair(s)
+//   P2  da1[c1][p] = sum_c2,tap dz2[c2][p - tap] * W2[c2][c1][tap]; dz1 = da1 * (a1 > 0)   thread = (row, c1, half of c2)
+//   P3  dW1[c1][c0][tap] += sum_pos dz1[c1][pos] * in[c0][pos + tap]          thread = (c1, c0, tap) item(s)
+template <int OD> struct GeoB {
+    static constexpr int DZ2 = 28;  // 25 padded to a 16-byte multiple
+    static constexpr int ROW_FLOATS = OD * kA1Stride + OD * DZ2 + 244 + OD * kA1Stride;  // a1, dz2, in, dz1/da1 partial
+    static constexpr int FIXED_FLOATS = OD * OD * 9;
+    static constexpr int RBB = ((kLdsBudget / 4 - FIXED_FLOATS) / ROW_FLOATS) < (kBlock / (2 * OD)) ? ((kLdsBudget / 4 - FIXED_FLOATS) / ROW_FLOATS)
+                                                                                                   : (kBlock / (2 * OD));
+    static constexpr size_t LDS_FLOATS = (size_t)FIXED_FLOATS + (size_t)RBB * ROW_FLOATS;
+    static constexpr int PAIRS = OD * OD, ITEMS = OD * 27;
+    static constexpr int PART = OD * OD * 9 + OD + OD * 27 + OD;  // dW2 | db2 | dW1 | db1
+};
+
+template <int OD>
+__global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__ obs, long obs_stride, long rows,
+                                                      const float *__restrict__ a1_save, const float *__restrict__ a2,
+                                                      long a2_stride, const float *__restrict__ g, long g_stride,
+                                                      const float *__restrict__ w2, float *__restrict__ part) {
+    using G = GeoB<OD>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *s_w2 = lds;                                  // [c2][tap][c1]
+    float *s_a1 = s_w2 + OD * OD * 9;                   // [RBB][OD][52]
+    float *s_dz2 = s_a1 + G::RBB * OD * kA1Stride;      // [RBB][OD][28]
+    float *s_in = s_dz2 + G::RBB * OD * G::DZ2;         // [RBB][244]
+    float *s_dz1 = s_in + G::RBB * 244;                 // [RBB][OD][52]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < OD * OD * 9; i += kBlock) {   // global (c2, c1, tap) -> LDS (c2, tap, c1)
+        const int c2 = i / (OD * 9), rem = i - c2 * OD * 9, c1 = rem / 9, tap = rem - c1 * 9;
+        s_w2[(c2 * 9 + tap) * OD + c1] = w2[i];
+    }
+    // persistent accumulators
+    float accW2[2][9], accW1[2], accB2 = 0.0f, accB1 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        accW1[q] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) accW2[q][k] = 0.0f;
+    }
+    const long n_blocks = (rows + G::RBB - 1) / G::RBB;
+    const long per = (n_blocks + gridDim.x - 1) / gridDim.x;
+    const long blk0 = (long)blockIdx.x * per, blk1 = min(n_blocks, blk0 + per);
+    for (long blk = blk0; blk < blk1; ++blk) {
+        const long row0 = blk * G::RBB;
+        const int rv = (int)min((long)G::RBB, rows - row0);
+        __syncthreads();
+        // ---- P0
+        for (int i = tid; i < rv * OD * 49; i += kBlock) {
+            const int rr = i / (OD * 49), rem = i - rr * OD * 49, c = rem / 49, k = rem - c * 49;
+            s_a1[(rr * OD + c) * kA1Stride + k] = a1_save[(row0 + rr) * OD * 49 + rem];
+        }
+        for (int i = tid; i < rv * OD * 25; i += kBlock) {
+            const int rr = i / (OD * 25), rem = i - rr * OD * 25, c = rem / 25, k = rem - c * 25;
+            const float act = a2[(row0 + rr) * a2_stride + rem];
+            s_dz2[(rr * OD + c) * G::DZ2 + k] = act > 0.0f ? g[(row0 + rr) * g_stride + rem] : 0.0f;
+        }
+        for (int i = tid; i < rv * 243; i += kBlock) {
+            const int rr = i / 243, pp = i - rr * 243;
+            s_in[rr * 244 + pp] = (float)obs[(row0 + rr) * obs_stride + pp];
+        }
+        __syncthreads();
+        // ---- P1: dW2 (and db2)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pair = tid + q * kBlock;
+            if (pair < G::PAIRS) {
+                const int c2 = pair / OD, c1 = pair - c2 * OD;
+                for (int rr = 0; rr < rv; ++rr) {
+                    float dz[G::DZ2], a[kA1Stride];
+                    const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + (rr * OD + c2) * G::DZ2, 16);
+                    const float4 *pa = (const float4 *)__builtin_assume_aligned(s_a1 + (rr * OD + c1) * kA1Stride, 16);
+#pragma unroll
+                    for (int j = 0; j < G::DZ2 / 4; ++j) { const float4 t = pd[j]; dz[4 * j] = t.x; dz[4 * j + 1] = t.y; dz[4 * j + 2] = t.z; dz[4 * j + 3] = t.w; }
+#pragma unroll
+                    for (int j = 0; j < kA1Stride / 4; ++j) { const float4 t = pa[j]; a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w; }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int x = 0; x < 5; ++x)
+#pragma unroll
+                                for (int y = 0; y < 5; ++y)
+                                    accW2[q][kx * 3 + ky] = fmaf(dz[x * 5 + y], a[(x + kx) * 7 + y + ky], accW2[q][kx * 3 + ky]);
+                }
+            }
+        }
+        if (tid < OD)
+            for (int rr = 0; rr < rv; ++rr)
+                for (int k = 0; k < 25; ++k) accB2 += s_dz2[(rr * OD + tid) * G::DZ2 + k];
+        // ---- P2: da1 partial sums over half of the c2 range; half 1 parks its partial in s_dz1
+        const int half = tid / (G::RBB * OD), rem2 = tid - half * G::RBB * OD;
+        const int r2 = rem2 / OD, c1b = rem2 - r2 * OD;
+        const bool p2 = half < 2 && r2 < rv;
+        float da[49];
+        if (p2) {
+#pragma unroll
+            for (int k = 0; k < 49; ++k) da[k] = 0.0f;
+            const int cbeg = half * (OD / 2), cend = cbeg + OD / 2;
+            for (int c2 = cbeg; c2 < cend; ++c2) {
+                float dz[G::DZ2], w[9];
+                const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + (r2 * OD + c2) * G::DZ2, 16);
+#pragma unroll
+                for (int j = 0; j < G::DZ2 / 4; ++j) { const float4 t = pd[j]; dz[4 * j] = t.x; dz[4 * j + 1] = t.y; dz[4 * j + 2] = t.z; dz[4 * j + 3] = t.w; }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) w[k] = s_w2[(c2 * 9 + k) * OD + c1b];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int x = 0; x < 5; ++x)
+#pragma unroll
+                            for (int y = 0; y < 5; ++y)
+                                da[(x + kx) * 7 + y + ky] = fmaf(dz[x * 5 + y], w[kx * 3 + ky], da[(x + kx) * 7 + y + ky]);
+            }
+            if (half == 1) {
+                float *dst = s_dz1 + (r2 * OD + c1b) * kA1Stride;
+#pragma unroll
+                for (int k = 0; k < 49; ++k) dst[k] = da[k];
+            }
+        }
+        __syncthreads();
+        if (p2 && half == 0) {
+            float *dst = s_dz1 + (r2 * OD + c1b) * kA1Stride;
+            const float *act = s_a1 + (r2 * OD + c1b) * kA1Stride;
+#pragma unroll
+            for (int k = 0; k < 49; ++k) dst[k] = act[k] > 0.0f ? da[k] + dst[k] : 0.0f;
+        }
+        __syncthreads();
+        // ---- P3: dW1 (and db1)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int item = tid + q * kBlock;
+            if (item < G::ITEMS) {
+                const int c1 = item / 27, rem3 = item - c1 * 27, c0 = rem3 / 9, tap = rem3 - c0 * 9, kx = tap / 3, ky = tap - kx * 3;
+                float acc = accW1[q];
+                for (int rr = 0; rr < rv; ++rr) {
+                    const float *dz = s_dz1 + (rr * OD + c1) * kA1Stride;
+                    const float *in = s_in + rr * 244 + c0 * 81 + kx * 9 + ky;
+#pragma unroll
+                    for (int x = 0; x < 7; ++x)
+#pragma unroll
+                        for (int y = 0; y < 7; ++y) acc = fmaf(dz[x * 7 + y], in[x * 9 + y], acc);
+                }
+                accW1[q] = acc;
+            }
+        }
+        if (tid >= kBlock - OD) {
+            const int c1 = tid - (kBlock - OD);
+            for (int rr = 0; rr < rv; ++rr)
+                for (int k = 0; k < 49; ++k) accB1 += s_dz1[(rr * OD + c1) * kA1Stride + k];
+        }
+    }
+    float *pp = part + (size_t)blockIdx.x * G::PART;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int pair = tid + q * kBlock;
+        if (pair < G::PAIRS)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) pp[pair * 9 + k] = accW2[q][k];
+        const int item = tid + q * kBlock;
+        if (item < G::ITEMS) pp[OD * OD * 9 + OD + item] = accW1[q];
+    }
+    if (tid < OD) pp[OD * OD * 9 + tid] = accB2;
+    if (tid >= kBlock - OD) pp[OD * OD * 9 + OD + OD * 27 + (tid - (kBlock - OD))] = accB1;
+}
+
 thread_local int g_last_hip = 0;
 
 template <int OD>
 int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w2,
            const float *b2, float *out, long out_stride, const int8_t *onehot, int n_actions, const float *mlp_w,
-           const float *mlp_b, hipStream_t s) {
+           const float *mlp_b, float *a1_save, hipStream_t s) {
     using G = Geo<OD>;
     const size_t lds = G::LDS_FLOATS * sizeof(float);
     static bool attr_set = false;
@@ -165,13 +345,33 @@ int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const
     const int grid = (int)(n_blocks < 256 ? n_blocks : 256);  // persistent: one 8-wave workgroup per CU keeps the weights resident
     (void)hipGetLastError();
     hipLaunchKernelGGL((k_conv9<OD>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, w1, b1, w2, b2, out, out_stride, onehot,
-                       n_actions, mlp_w, mlp_b);
+                       n_actions, mlp_w, mlp_b, a1_save);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_last_hip = (int)e;
         if (getenv("DMFB_VEC_DEBUG")) fprintf(stderr, "crnn_ops: launch failed: %s\n", hipGetErrorString(e));
         return CRNN_ERR_HIP;
     }
+    return CRNN_OK;
+}
+
+
+template <int OD>
+int launch_bwd(const int8_t *obs, long obs_stride, long rows, const float *a1_save, const float *a2, long a2_stride,
+               const float *g, long g_stride, const float *w2, float *part, int grid, hipStream_t s) {
+    using G = GeoB<OD>;
+    const size_t lds = G::LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv9_bwd<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
+        attr_set = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((k_conv9_bwd<OD>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, a1_save, a2, a2_stride, g, g_stride,
+                       w2, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
     return CRNN_OK;
 }
 
@@ -184,8 +384,8 @@ int crnn_conv9_forward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, co
     if (!d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_out || rows < 0 || obs_stride < 243 || out_stride < od * 25)
         return CRNN_ERR_BAD_ARG;
     if (rows == 0) return CRNN_OK;
-    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
-    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
 }
 
@@ -196,8 +396,31 @@ int crnn_front9_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d
         out_stride < od * 25 + 10 || n_actions < 0 || n_actions > 16)
         return CRNN_ERR_BAD_ARG;
     if (rows == 0) return CRNN_OK;
-    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
-    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
+    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, nullptr, (hipStream_t)stream);
+    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, nullptr, (hipStream_t)stream);
+    return CRNN_ERR_UNSUPPORTED;
+}
+
+int crnn_conv9_forward_train(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_w1, const float *d_b1,
+                             const float *d_w2, const float *d_b2, int od, float *d_out, int64_t out_stride, float *d_a1_save,
+                             void *stream) {
+    if (!d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_out || !d_a1_save || rows < 0 || obs_stride < 243 || out_stride < od * 25)
+        return CRNN_ERR_BAD_ARG;
+    if (rows == 0) return CRNN_OK;
+    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, d_a1_save, (hipStream_t)stream);
+    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, d_a1_save, (hipStream_t)stream);
+    return CRNN_ERR_UNSUPPORTED;
+}
+
+int crnn_conv9_backward_parts(int od) { return od * od * 9 + od + od * 27 + od; }
+
+int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_a1_save, const float *d_out,
+                        int64_t out_stride, const float *d_grad_out, int64_t grad_stride, const float *d_w2, int od,
+                        float *d_part, int n_part, void *stream) {
+    if (!d_obs || !d_a1_save || !d_out || !d_grad_out || !d_w2 || !d_part || rows <= 0 || n_part < 1 || n_part > 256)
+        return CRNN_ERR_BAD_ARG;
+    if (od == 24) return launch_bwd<24>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, (hipStream_t)stream);
+    if (od == 32) return launch_bwd<32>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
 }
 

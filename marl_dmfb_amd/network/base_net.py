@@ -44,6 +44,59 @@ class _ConvGemm(torch.autograd.Function):
         return gcols, gw, g.sum(0)
 
 
+class _ConvFront9(torch.autograd.Function):
+    """conv1+ReLU+conv2+ReLU of int8 observation rows for fov 9 through the hand-written HIP kernels
+    (include/crnn_ops.h: crnn_conv9_forward_train / crnn_conv9_backward), with gradients for the four
+    parameter tensors.  Used for the eval network inside VDN.learn on the GPU."""
+
+    N_PART = 256
+
+    @staticmethod
+    def forward(ctx, obs_i8, w1, b1, w2, b2):
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.crnn_ops()
+        obs_i8 = obs_i8.contiguous()
+        R, od = obs_i8.shape[0], w1.shape[0]
+        out = torch.empty((R, od * 25), dtype=torch.float32, device=obs_i8.device)
+        a1 = torch.empty((R, od * 49), dtype=torch.float32, device=obs_i8.device)
+        w1c, b1c, w2c, b2c = w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
+        stream = C.c_void_p(torch.cuda.current_stream(obs_i8.device).cuda_stream)
+        rc = lib.crnn_conv9_forward_train(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), R, C.c_void_p(w1c.data_ptr()),
+                                          C.c_void_p(b1c.data_ptr()), C.c_void_p(w2c.data_ptr()), C.c_void_p(b2c.data_ptr()),
+                                          od, C.c_void_p(out.data_ptr()), out.stride(0), C.c_void_p(a1.data_ptr()), stream)
+        if rc != 0:
+            raise RuntimeError('crnn_conv9_forward_train failed: %d' % rc)
+        ctx.save_for_backward(obs_i8, a1, out, w2c)
+        ctx.shapes = (w1.shape, w2.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.crnn_ops()
+        obs_i8, a1, out, w2c = ctx.saved_tensors
+        (s1, s2) = ctx.shapes
+        od, R = s1[0], obs_i8.shape[0]
+        g = g.contiguous()
+        plen = lib.crnn_conv9_backward_parts(od)
+        part = torch.empty((_ConvFront9.N_PART, plen), dtype=torch.float32, device=g.device)
+        stream = C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
+        rc = lib.crnn_conv9_backward(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), R, C.c_void_p(a1.data_ptr()),
+                                     C.c_void_p(out.data_ptr()), out.stride(0), C.c_void_p(g.data_ptr()), g.stride(0),
+                                     C.c_void_p(w2c.data_ptr()), od, C.c_void_p(part.data_ptr()), _ConvFront9.N_PART, stream)
+        if rc != 0:
+            raise RuntimeError('crnn_conv9_backward failed: %d' % rc)
+        tot = part.sum(dim=0)
+        n2 = od * od * 9
+        g_w2 = tot[:n2].view(s2)
+        g_b2 = tot[n2:n2 + od]
+        g_w1 = tot[n2 + od:n2 + od + od * 27].view(s1)
+        g_b1 = tot[n2 + od + od * 27:]
+        return None, g_w1, g_b1, g_w2, g_b2
+
+
 class _GRUSeq(torch.autograd.Function):
     """GRU cell unrolled over a whole sequence as ONE autograd node (GPU only).
 
@@ -218,6 +271,19 @@ class CRNN(nn.Module):
         if rc != 0:
             raise RuntimeError('crnn_front9_forward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
         return out
+
+    def features_obs_train(self, obs_i8, la_rows):
+        """GRU input rows for the eval network inside learn (gradients flow to every parameter):
+        HIP conv front end with its own backward + the small vector MLP in torch."""
+        c1, c2 = self.convs[0], self.convs[1]
+        pix = _ConvFront9.apply(obs_i8, c1.weight, c1.bias, c2.weight, c2.bias)
+        vec = torch.cat([obs_i8[:, self.n_pixel:].float(), la_rows.float()], dim=1)
+        return torch.cat([pix, f.relu(self.mlp1(vec))], dim=1)
+
+    def _hip_train_ok(self, obs_i8):
+        return (self.conv_impl == 'gemm' and obs_i8.is_cuda and obs_i8.dtype == torch.int8 and torch.is_grad_enabled()
+                and self.input_dim[:3] == (3, 9, 9) and len(self.convs) == 2 and self.convs[0].out_channels in (24, 32)
+                and self.convs[0] is not self.convs[1])
 
     def _hip_conv_ok(self, obs_i8):
         return (self.conv_impl == 'gemm' and obs_i8.is_cuda and obs_i8.dtype == torch.int8 and not torch.is_grad_enabled()

@@ -45,3 +45,34 @@ def test_forward_obs_uses_kernel_and_matches_reference_forward():
         q2, h2 = cpu(torch.cat([obs.float(), la.float()], dim=1).cpu(), h.cpu())
     np.testing.assert_allclose(q1.cpu().numpy(), q2.numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(h1.cpu().numpy(), h2.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('od,rows', [(24, 20000), (32, 5003), (24, 11)])
+def test_conv9_training_pair_matches_torch_autograd(od, rows):
+    """Forward (saving activations) + backward kernels against torch autograd on conv2d (float64 reference)."""
+    from marl_dmfb_amd.network.base_net import CRNN, _ConvFront9
+    a = types.SimpleNamespace(obs_shape=(3, 9, 9, 2, 245), hyper_hidden_dim=od, rnn_hidden_dim=128, n_actions=5, fov=9)
+    torch.manual_seed(od * 7 + rows)
+    net = CRNN(a).cuda()
+    obs = torch.randint(-3, 8, (rows, 245), dtype=torch.int8, device='cuda')
+    gout = torch.randn(rows, od * 25, device='cuda')
+    c1, c2 = net.convs
+    pix = _ConvFront9.apply(obs, c1.weight, c1.bias, c2.weight, c2.bias)
+    (pix * gout).sum().backward()
+    got = [p.grad.detach().cpu().clone() for p in (c1.weight, c1.bias, c2.weight, c2.bias)]
+    ref_net = CRNN(a).double()
+    ref_net.load_state_dict({k: v.double().cpu() for k, v in net.state_dict().items()})
+    x = obs[:, :243].double().view(rows, 3, 9, 9).cpu()
+    for conv in ref_net.convs:
+        x = torch.relu(conv(x))
+    np.testing.assert_allclose(pix.detach().cpu().numpy(), x.reshape(rows, -1).detach().numpy(), rtol=1e-4, atol=1e-4)
+    (x.reshape(rows, -1) * gout.double().cpu()).sum().backward()
+    rc1, rc2 = ref_net.convs
+    # Tolerance: relative L2 error < 2e-3 and max abs error < 1e-2 x max|grad| per tensor.  The reference is
+    # float64; an fp32 pre-activation within rounding distance of zero can flip its ReLU mask (observed: one
+    # element in 12 million), which moves a gradient sum by that element's whole contribution.
+    for g, r in zip(got, (rc1.weight.grad, rc1.bias.grad, rc2.weight.grad, rc2.bias.grad)):
+        r = r.float().numpy()
+        g = g.numpy()
+        assert np.linalg.norm(g - r) <= 2e-3 * np.linalg.norm(r)
+        assert np.abs(g - r).max() <= 1e-2 * np.abs(r).max()
