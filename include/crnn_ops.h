@@ -39,18 +39,20 @@ int crnn_front9_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d
                         const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
                         const float *d_mlp_b, int od, float *d_out, int64_t out_stride, void *stream);
 /* Training pair for the eval network of VDN.learn (policy/vdn.py:174-191): same forward, additionally
- * saving the conv1 activations d_a1_save float32[rows][od*49]; the backward forms the gradients of the
- * four parameter tensors (the observation needs none) as n_part partial vectors
- * d_part float32[n_part][crnn_conv9_backward_parts(od)] laid out dW2[od][od][3][3] | db2[od] | dW1[od][3][3][3] |
- * db1[od]; the caller adds the partial vectors (n_part <= 256, one per workgroup; deterministic).
+ * saving the conv1 activations d_a1_save float32[rows][crnn_conv9_a1_floats(od)]; the backward forms the
+ * gradients of the four parameter tensors (the observation needs none): one workgroup per partial
+ * vector accumulates over its rows into d_part float32[n_part][crnn_conv9_backward_parts(od)] (scratch,
+ * n_part <= 256), then a second small kernel adds the partial vectors (fixed order: deterministic) into
+ * d_grads float32[od*od*9 + od + od*27 + od] = dW2[od][od][3][3] | db2[od] | dW1[od][3][3][3] | db1[od].
  * d_out is the forward's output (its sign is the ReLU mask), d_grad_out the gradient w.r.t. it. */
 int crnn_conv9_forward_train(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_w1, const float *d_b1,
                              const float *d_w2, const float *d_b2, int od, float *d_out, int64_t out_stride, float *d_a1_save,
                              void *stream);
 int crnn_conv9_backward_parts(int od);
+int crnn_conv9_a1_floats(int od);
 int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_a1_save, const float *d_out,
                         int64_t out_stride, const float *d_grad_out, int64_t grad_stride, const float *d_w2, int od,
-                        float *d_part, int n_part, void *stream);
+                        float *d_part, int n_part, float *d_grads, void *stream);
 int crnn_last_hip_error(void);
 
 #ifdef __cplusplus

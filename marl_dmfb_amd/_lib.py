@@ -145,7 +145,8 @@ def crnn_ops():
     lib.crnn_front9_forward.argtypes = [vp, i64, vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, i64, vp]
     lib.crnn_conv9_forward_train.argtypes = [vp, i64, i64, vp, vp, vp, vp, C.c_int, vp, i64, vp, vp]
     lib.crnn_conv9_backward_parts.argtypes = [C.c_int]
-    lib.crnn_conv9_backward.argtypes = [vp, i64, i64, vp, vp, i64, vp, i64, vp, C.c_int, vp, C.c_int, vp]
+    lib.crnn_conv9_a1_floats.argtypes = [C.c_int]
+    lib.crnn_conv9_backward.argtypes = [vp, i64, i64, vp, vp, i64, vp, i64, vp, C.c_int, vp, C.c_int, vp, vp]
     lib.crnn_last_hip_error.argtypes = []
     lib._typed = True
     return lib

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9(const int8_t *__restrict__ obs
 #pragma unroll
                 for (int y = 0; y < 7; ++y) a1[x * 7 + y] = fmaxf(acc[y], 0.0f);
                 if (a1_save) {  // training: keep the conv1 activations for the backward kernel
-                    float *sv = a1_save + ((row0 + r) * OD + c) * 49 + x * 7;
+                    float *sv = a1_save + ((row0 + r) * OD + c) * kA1Stride + x * 7;  // padded like the LDS image
 #pragma unroll
                     for (int y = 0; y < 7; ++y) sv[y] = fmaxf(acc[y], 0.0f);
                 }
@@ -169,8 +169,16 @@ template <int OD> struct GeoB {
     static constexpr int RBB = ((kLdsBudget / 4 - FIXED_FLOATS) / ROW_FLOATS) < (kBlock / (2 * OD)) ? ((kLdsBudget / 4 - FIXED_FLOATS) / ROW_FLOATS)
                                                                                                    : (kBlock / (2 * OD));
     static constexpr size_t LDS_FLOATS = (size_t)FIXED_FLOATS + (size_t)RBB * ROW_FLOATS;
-    static constexpr int PAIRS = OD * OD, ITEMS = OD * 27;
-    static constexpr int PART = OD * OD * 9 + OD + OD * 27 + OD;  // dW2 | db2 | dW1 | db1
+    static constexpr int PAIRS = OD * OD;
+    // (c2, c1) pairs beyond the first kBlock: either exactly one more per thread (od 32) or a remainder that is
+    // spread over all threads by giving each (pair, row slice) to a different thread (od 24: 64 pairs x 8 slices)
+    static constexpr int EXTRA = PAIRS - kBlock;
+    static constexpr int XSLICES = EXTRA > 0 ? kBlock / EXTRA : 1;
+    // dW1 work items (c1, c0, kx) x row slices
+    static constexpr int ITEMS3 = OD * 9;
+    static constexpr int RS3 = kBlock / ITEMS3;  // 2 (od 24) or 1 (od 32)
+    // partial vector: dW2 first pass [kBlock][9] | dW2 extra [kBlock][9] | db2 [OD] | dW1 [kBlock][3] | db1 [OD]
+    static constexpr int PART = kBlock * 9 + kBlock * 9 + OD + kBlock * 3 + OD;
 };
 
 template <int OD>
@@ -190,14 +198,22 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         const int c2 = i / (OD * 9), rem = i - c2 * OD * 9, c1 = rem / 9, tap = rem - c1 * 9;
         s_w2[(c2 * 9 + tap) * OD + c1] = w2[i];
     }
-    // persistent accumulators
-    float accW2[2][9], accW1[2], accB2 = 0.0f, accB1 = 0.0f;
+    float accA[9], accX[9], accW1[3], accB2 = 0.0f, accB1 = 0.0f;  // persistent over all rows of the workgroup
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        accW1[q] = 0.0f;
+    for (int k = 0; k < 9; ++k) { accA[k] = 0.0f; accX[k] = 0.0f; }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) accW2[q][k] = 0.0f;
-    }
+    for (int k = 0; k < 3; ++k) accW1[k] = 0.0f;
+    // first-pass pair of this thread, extra-pass (pair, slice), dW1 (item, slice)
+    const int pa_c2 = tid / OD, pa_c1 = tid - pa_c2 * OD;
+    const bool pa_on = tid < G::PAIRS;
+    const int px_pair = G::EXTRA > 0 ? kBlock + (G::EXTRA == kBlock ? tid : tid % (G::EXTRA > 0 ? G::EXTRA : 1)) : 0;
+    const int px_slice = (G::EXTRA > 0 && G::EXTRA != kBlock) ? tid / G::EXTRA : 0;
+    const bool px_on = G::EXTRA > 0 && px_pair < G::PAIRS && px_slice < G::XSLICES;
+    const int px_c2 = px_pair / OD, px_c1 = px_pair - px_c2 * OD;
+    const int i3 = tid % G::ITEMS3, s3 = tid / G::ITEMS3;
+    const bool p3_on = s3 < G::RS3;
+    const int c1_3 = i3 / 9, c0_3 = (i3 - c1_3 * 9) / 3, kx_3 = i3 - c1_3 * 9 - c0_3 * 3;
+
     const long n_blocks = (rows + G::RBB - 1) / G::RBB;
     const long per = (n_blocks + gridDim.x - 1) / gridDim.x;
     const long blk0 = (long)blockIdx.x * per, blk1 = min(n_blocks, blk0 + per);
@@ -205,10 +221,11 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         const long row0 = blk * G::RBB;
         const int rv = (int)min((long)G::RBB, rows - row0);
         __syncthreads();
-        // ---- P0
-        for (int i = tid; i < rv * OD * 49; i += kBlock) {
-            const int rr = i / (OD * 49), rem = i - rr * OD * 49, c = rem / 49, k = rem - c * 49;
-            s_a1[(rr * OD + c) * kA1Stride + k] = a1_save[(row0 + rr) * OD * 49 + rem];
+        // ---- P0: stage the rows (a1 is saved in the padded LDS layout: straight 16-byte copies)
+        {
+            const float4 *src = (const float4 *)(a1_save + row0 * OD * kA1Stride);
+            float4 *dst = (float4 *)s_a1;
+            for (int i = tid; i < rv * OD * kA1Stride / 4; i += kBlock) dst[i] = src[i];
         }
         for (int i = tid; i < rv * OD * 25; i += kBlock) {
             const int rr = i / (OD * 25), rem = i - rr * OD * 25, c = rem / 25, k = rem - c * 25;
@@ -221,31 +238,28 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         }
         __syncthreads();
         // ---- P1: dW2 (and db2)
+        auto pair_rows = [&](int c2, int c1, int r_begin, int r_step, float (&acc)[9]) {
+            for (int rr = r_begin; rr < rv; rr += r_step) {
+                float dz[G::DZ2], a[kA1Stride];
+                const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + (rr * OD + c2) * G::DZ2, 16);
+                const float4 *pa = (const float4 *)__builtin_assume_aligned(s_a1 + (rr * OD + c1) * kA1Stride, 16);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int pair = tid + q * kBlock;
-            if (pair < G::PAIRS) {
-                const int c2 = pair / OD, c1 = pair - c2 * OD;
-                for (int rr = 0; rr < rv; ++rr) {
-                    float dz[G::DZ2], a[kA1Stride];
-                    const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + (rr * OD + c2) * G::DZ2, 16);
-                    const float4 *pa = (const float4 *)__builtin_assume_aligned(s_a1 + (rr * OD + c1) * kA1Stride, 16);
+                for (int j = 0; j < G::DZ2 / 4; ++j) { const float4 t = pd[j]; dz[4 * j] = t.x; dz[4 * j + 1] = t.y; dz[4 * j + 2] = t.z; dz[4 * j + 3] = t.w; }
 #pragma unroll
-                    for (int j = 0; j < G::DZ2 / 4; ++j) { const float4 t = pd[j]; dz[4 * j] = t.x; dz[4 * j + 1] = t.y; dz[4 * j + 2] = t.z; dz[4 * j + 3] = t.w; }
+                for (int j = 0; j < kA1Stride / 4; ++j) { const float4 t = pa[j]; a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w; }
 #pragma unroll
-                    for (int j = 0; j < kA1Stride / 4; ++j) { const float4 t = pa[j]; a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w; }
+                for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
+                    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                        for (int ky = 0; ky < 3; ++ky)
+                        for (int x = 0; x < 5; ++x)
 #pragma unroll
-                            for (int x = 0; x < 5; ++x)
-#pragma unroll
-                                for (int y = 0; y < 5; ++y)
-                                    accW2[q][kx * 3 + ky] = fmaf(dz[x * 5 + y], a[(x + kx) * 7 + y + ky], accW2[q][kx * 3 + ky]);
-                }
+                            for (int y = 0; y < 5; ++y)
+                                acc[kx * 3 + ky] = fmaf(dz[x * 5 + y], a[(x + kx) * 7 + y + ky], acc[kx * 3 + ky]);
             }
-        }
+        };
+        if (pa_on) pair_rows(pa_c2, pa_c1, 0, 1, accA);
+        if (px_on) pair_rows(px_c2, px_c1, px_slice, (G::EXTRA == kBlock) ? 1 : G::XSLICES, accX);
         if (tid < OD)
             for (int rr = 0; rr < rv; ++rr)
                 for (int k = 0; k < 25; ++k) accB2 += s_dz2[(rr * OD + tid) * G::DZ2 + k];
@@ -289,22 +303,24 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
             for (int k = 0; k < 49; ++k) dst[k] = act[k] > 0.0f ? da[k] + dst[k] : 0.0f;
         }
         __syncthreads();
-        // ---- P3: dW1 (and db1)
+        // ---- P3: dW1[c1][c0][kx][0..2] over this thread's row slice (and db1)
+        if (p3_on) {
+            for (int rr = s3; rr < rv; rr += G::RS3) {
+                float dz[kA1Stride];
+                const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz1 + (rr * OD + c1_3) * kA1Stride, 16);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int item = tid + q * kBlock;
-            if (item < G::ITEMS) {
-                const int c1 = item / 27, rem3 = item - c1 * 27, c0 = rem3 / 9, tap = rem3 - c0 * 9, kx = tap / 3, ky = tap - kx * 3;
-                float acc = accW1[q];
-                for (int rr = 0; rr < rv; ++rr) {
-                    const float *dz = s_dz1 + (rr * OD + c1) * kA1Stride;
-                    const float *in = s_in + rr * 244 + c0 * 81 + kx * 9 + ky;
+                for (int j = 0; j < kA1Stride / 4; ++j) { const float4 t = pd[j]; dz[4 * j] = t.x; dz[4 * j + 1] = t.y; dz[4 * j + 2] = t.z; dz[4 * j + 3] = t.w; }
+                const float *in = s_in + rr * 244 + c0_3 * 81 + kx_3 * 9;
 #pragma unroll
-                    for (int x = 0; x < 7; ++x)
+                for (int x = 0; x < 7; ++x) {
+                    float v[9];
 #pragma unroll
-                        for (int y = 0; y < 7; ++y) acc = fmaf(dz[x * 7 + y], in[x * 9 + y], acc);
+                    for (int y = 0; y < 9; ++y) v[y] = in[x * 9 + y];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int y = 0; y < 7; ++y) accW1[ky] = fmaf(dz[x * 7 + y], v[y + ky], accW1[ky]);
                 }
-                accW1[q] = acc;
             }
         }
         if (tid >= kBlock - OD) {
@@ -315,16 +331,40 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     }
     float *pp = part + (size_t)blockIdx.x * G::PART;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int pair = tid + q * kBlock;
-        if (pair < G::PAIRS)
+    for (int k = 0; k < 9; ++k) { pp[tid * 9 + k] = accA[k]; pp[kBlock * 9 + tid * 9 + k] = accX[k]; }
+    if (tid < OD) pp[kBlock * 18 + tid] = accB2;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) pp[pair * 9 + k] = accW2[q][k];
-        const int item = tid + q * kBlock;
-        if (item < G::ITEMS) pp[OD * OD * 9 + OD + item] = accW1[q];
+    for (int k = 0; k < 3; ++k) pp[kBlock * 18 + OD + tid * 3 + k] = accW1[k];
+    if (tid >= kBlock - OD) pp[kBlock * 18 + OD + kBlock * 3 + (tid - (kBlock - OD))] = accB1;
+}
+
+// Sum of the partial vectors -> the four gradient tensors (tiny: <= 256 x ~11k floats), one thread per output.
+template <int OD>
+__global__ void k_conv9_bwd_reduce(const float *__restrict__ part, int n_part, float *__restrict__ grads) {
+    using G = GeoB<OD>;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n2 = OD * OD * 9, nb = OD, n1 = OD * 27;
+    if (i >= n2 + nb + n1 + nb) return;
+    float acc = 0.0f;
+    if (i < n2) {                                        // dW2[c2][c1][tap]
+        const int pair = i / 9, tap = i - pair * 9;
+        for (int b = 0; b < n_part; ++b) {
+            const float *pp = part + (size_t)b * G::PART;
+            if (pair < kBlock) acc += pp[pair * 9 + tap];
+            else if (G::EXTRA == kBlock) acc += pp[kBlock * 9 + (pair - kBlock) * 9 + tap];
+            else
+                for (int sl = 0; sl < G::XSLICES; ++sl) acc += pp[kBlock * 9 + (sl * G::EXTRA + (pair - kBlock)) * 9 + tap];
+        }
+    } else if (i < n2 + nb) {                            // db2
+        for (int b = 0; b < n_part; ++b) acc += part[(size_t)b * G::PART + kBlock * 18 + (i - n2)];
+    } else if (i < n2 + nb + n1) {                       // dW1[c1][c0][kx][ky]: item = (c1*3+c0)*3+kx, ky
+        const int j = i - n2 - nb, item = j / 3, ky = j - item * 3;
+        for (int b = 0; b < n_part; ++b)
+            for (int sl = 0; sl < G::RS3; ++sl) acc += part[(size_t)b * G::PART + kBlock * 18 + OD + (sl * G::ITEMS3 + item) * 3 + ky];
+    } else {                                             // db1
+        for (int b = 0; b < n_part; ++b) acc += part[(size_t)b * G::PART + kBlock * 18 + OD + kBlock * 3 + (i - n2 - nb - n1)];
     }
-    if (tid < OD) pp[OD * OD * 9 + tid] = accB2;
-    if (tid >= kBlock - OD) pp[OD * OD * 9 + OD + OD * 27 + (tid - (kBlock - OD))] = accB1;
+    grads[i] = acc;
 }
 
 thread_local int g_last_hip = 0;
@@ -358,7 +398,7 @@ int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const
 
 template <int OD>
 int launch_bwd(const int8_t *obs, long obs_stride, long rows, const float *a1_save, const float *a2, long a2_stride,
-               const float *g, long g_stride, const float *w2, float *part, int grid, hipStream_t s) {
+               const float *g, long g_stride, const float *w2, float *part, int grid, float *grads, hipStream_t s) {
     using G = GeoB<OD>;
     const size_t lds = G::LDS_FLOATS * sizeof(float);
     static bool attr_set = false;
@@ -370,6 +410,8 @@ int launch_bwd(const int8_t *obs, long obs_stride, long rows, const float *a1_sa
     (void)hipGetLastError();
     hipLaunchKernelGGL((k_conv9_bwd<OD>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, a1_save, a2, a2_stride, g, g_stride,
                        w2, part);
+    const int n_out = OD * OD * 9 + OD + OD * 27 + OD;
+    hipLaunchKernelGGL((k_conv9_bwd_reduce<OD>), dim3((n_out + 255) / 256), dim3(256), 0, s, part, grid, grads);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
     return CRNN_OK;
@@ -412,15 +454,16 @@ int crnn_conv9_forward_train(const int8_t *d_obs, int64_t obs_stride, int64_t ro
     return CRNN_ERR_UNSUPPORTED;
 }
 
-int crnn_conv9_backward_parts(int od) { return od * od * 9 + od + od * 27 + od; }
+int crnn_conv9_backward_parts(int od) { return od == 24 ? GeoB<24>::PART : od == 32 ? GeoB<32>::PART : CRNN_ERR_UNSUPPORTED; }
+int crnn_conv9_a1_floats(int od) { return od * kA1Stride; }
 
 int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_a1_save, const float *d_out,
                         int64_t out_stride, const float *d_grad_out, int64_t grad_stride, const float *d_w2, int od,
-                        float *d_part, int n_part, void *stream) {
-    if (!d_obs || !d_a1_save || !d_out || !d_grad_out || !d_w2 || !d_part || rows <= 0 || n_part < 1 || n_part > 256)
+                        float *d_part, int n_part, float *d_grads, void *stream) {
+    if (!d_obs || !d_a1_save || !d_out || !d_grad_out || !d_w2 || !d_part || !d_grads || rows <= 0 || n_part < 1 || n_part > 256)
         return CRNN_ERR_BAD_ARG;
-    if (od == 24) return launch_bwd<24>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, (hipStream_t)stream);
-    if (od == 32) return launch_bwd<32>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, (hipStream_t)stream);
+    if (od == 24) return launch_bwd<24>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, (hipStream_t)stream);
+    if (od == 32) return launch_bwd<32>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
 }
 

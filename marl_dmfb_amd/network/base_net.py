@@ -59,7 +59,7 @@ class _ConvFront9(torch.autograd.Function):
         obs_i8 = obs_i8.contiguous()
         R, od = obs_i8.shape[0], w1.shape[0]
         out = torch.empty((R, od * 25), dtype=torch.float32, device=obs_i8.device)
-        a1 = torch.empty((R, od * 49), dtype=torch.float32, device=obs_i8.device)
+        a1 = torch.empty((R, lib.crnn_conv9_a1_floats(od)), dtype=torch.float32, device=obs_i8.device)
         w1c, b1c, w2c, b2c = w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
         stream = C.c_void_p(torch.cuda.current_stream(obs_i8.device).cuda_stream)
         rc = lib.crnn_conv9_forward_train(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), R, C.c_void_p(w1c.data_ptr()),
@@ -82,14 +82,15 @@ class _ConvFront9(torch.autograd.Function):
         g = g.contiguous()
         plen = lib.crnn_conv9_backward_parts(od)
         part = torch.empty((_ConvFront9.N_PART, plen), dtype=torch.float32, device=g.device)
+        n2 = od * od * 9
+        tot = torch.empty(n2 + od + od * 27 + od, dtype=torch.float32, device=g.device)
         stream = C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
         rc = lib.crnn_conv9_backward(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), R, C.c_void_p(a1.data_ptr()),
                                      C.c_void_p(out.data_ptr()), out.stride(0), C.c_void_p(g.data_ptr()), g.stride(0),
-                                     C.c_void_p(w2c.data_ptr()), od, C.c_void_p(part.data_ptr()), _ConvFront9.N_PART, stream)
+                                     C.c_void_p(w2c.data_ptr()), od, C.c_void_p(part.data_ptr()), _ConvFront9.N_PART,
+                                     C.c_void_p(tot.data_ptr()), stream)
         if rc != 0:
             raise RuntimeError('crnn_conv9_backward failed: %d' % rc)
-        tot = part.sum(dim=0)
-        n2 = od * od * 9
         g_w2 = tot[:n2].view(s2)
         g_b2 = tot[n2:n2 + od]
         g_w1 = tot[n2 + od:n2 + od + od * 27].view(s1)

@@ -84,7 +84,7 @@ def test_crnn_ops_library_exports():
     txt = open(os.path.join(ROOT, 'include', 'crnn_ops.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     names = sorted(set(re.findall(r'\b(crnn_[a-z_0-9]+)\s*\(', txt)))
-    assert names == ['crnn_conv9_backward', 'crnn_conv9_backward_parts', 'crnn_conv9_forward', 'crnn_conv9_forward_train',
+    assert names == ['crnn_conv9_a1_floats', 'crnn_conv9_backward', 'crnn_conv9_backward_parts', 'crnn_conv9_forward', 'crnn_conv9_forward_train',
                      'crnn_front9_forward', 'crnn_last_hip_error']
     for n in names:
         assert hasattr(lib, n)
