@@ -69,3 +69,32 @@ class Trainer:
         np.save(self.save_path + '/constraints_{}'.format(i), self.episode_constraints)
         np.save(self.save_path + '/success_rate_{}'.format(i), self.success_rate)
         np.save(self.save_path + '/runtime_{}'.format(i), self.time_cost)
+
+
+def main(argv=None):
+    """`python -m marl_dmfb_amd.train dmfb --drop_num=4 --fov=9 [--n_envs 4096] [--dist]` -- the reference's
+    `python train.py dmfb --drop_num=4 --fov=9` (train.py:161-169) on the vectorised HIP env."""
+    import torch.distributed as dist
+    from .common.arguments import get_train_args
+    args = get_train_args(argv)
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if args.dist and world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if args.name == 'dmfb':
+        from .env.dmfb import VecDMFB
+        env = VecDMFB(args.width, args.length, args.drop_num, args.block_num, fov=args.fov, stall=args.stall,
+                      n_envs=args.n_envs, seed=args.seed, env_id0=rank * args.n_envs)
+    else:
+        from .env.meda import VecMEDA
+        env = VecMEDA(args.width, args.length, args.drop_num, fov=args.fov, n_envs=args.n_envs, seed=args.seed,
+                      env_id0=rank * args.n_envs, version=2 if args.version == '0.2' else 0)
+    args.__dict__.update(env.get_env_info())
+    args.device = str(env.device)
+    args.buffer_size = max(args.buffer_size, 4 * args.n_envs)
+    Trainer(env, args).run(online_evaluate=args.online_eval)
+
+
+if __name__ == '__main__':
+    main()
