@@ -287,21 +287,23 @@ struct Tile {
 };
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 // LDS bytes of a workgroup: obs block (0 for the step-only launch) + pos/goal + flags
+// The obs block sits in LDS at the SAME 16-byte phase as its destination in HBM (shift = offset & 15), so
+// the body of a tile streams out with aligned 16-byte accesses for ANY tile size (16 bytes of slack).
 __host__ __device__ inline size_t tile_lds_bytes(int T, int n, int obs_len, bool with_obs) {
-    return (with_obs ? align16((size_t)T * n * obs_len) : 0) + (size_t)T * n * 4 + align16((size_t)T);
+    return (with_obs ? align16((size_t)T * n * obs_len + 16) : 0) + (size_t)T * n * 4 + align16((size_t)T);
 }
-__device__ __forceinline__ Tile carve(unsigned char *smem, int T, int n, int obs_len, bool with_obs) {
+__device__ __forceinline__ Tile carve(unsigned char *smem, int T, int n, int obs_len, bool with_obs, int shift = 0) {
     Tile t;
-    t.obs = (int8_t *)smem;
-    const size_t off = with_obs ? align16((size_t)T * n * obs_len) : 0;
+    t.obs = (int8_t *)smem + shift;
+    const size_t off = with_obs ? align16((size_t)T * n * obs_len + 16) : 0;
     t.pos = (uint16_t *)(smem + off);
     t.goal = t.pos + (size_t)T * n;
     t.flag = (uint8_t *)(t.goal + (size_t)T * n);
     return t;
 }
 
-__device__ __forceinline__ void zero_tile(const Tile &t, int bytes16, int tid, int nthreads) {
-    uint4 *p = (uint4 *)t.obs;
+__device__ __forceinline__ void zero_tile(unsigned char *smem, int bytes16, int tid, int nthreads) {
+    uint4 *p = (uint4 *)smem;
     const uint4 z = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < bytes16; i += nthreads) p[i] = z;
 }
@@ -365,14 +367,17 @@ __device__ __forceinline__ void scatter_tile(const DevCfg &c, const DevPtrs &p, 
     }
 }
 
-// stream the finished tile to HBM: 16 bytes per lane, fully coalesced
-__device__ __forceinline__ void copy_tile_out(const Tile &t, int8_t *gobs, size_t tile_off, int bytes, int tid,
+// stream the finished tile to HBM: head (< 16 bytes) and tail by bytes, body 16 bytes per lane, coalesced
+__device__ __forceinline__ void copy_tile_out(const Tile &t, int shift, int8_t *gobs, size_t tile_off, int bytes, int tid,
                                               int nthreads) {
-    const int n16 = bytes >> 4;
-    const uint4 *src = (const uint4 *)t.obs;
-    uint4 *dst = (uint4 *)(gobs + tile_off);
+    const int head = (16 - shift) & 15;
+    const int hb = head < bytes ? head : bytes;
+    for (int b = tid; b < hb; b += nthreads) gobs[tile_off + b] = t.obs[b];
+    const int n16 = (bytes - hb) >> 4;
+    const uint4 *src = (const uint4 *)(t.obs + hb);
+    uint4 *dst = (uint4 *)(gobs + tile_off + hb);
     for (int i = tid; i < n16; i += nthreads) dst[i] = src[i];
-    for (int b = (n16 << 4) + tid; b < bytes; b += nthreads) gobs[tile_off + b] = t.obs[b];
+    for (int b = hb + (n16 << 4) + tid; b < bytes; b += nthreads) gobs[tile_off + b] = t.obs[b];
 }
 
 template <typename T> __device__ __forceinline__ int load_action(const void *a, size_t idx) {
@@ -393,9 +398,10 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = c.T, E = c.E;
     const bool want_obs = a.out.d_obs != nullptr;
-    const Tile t = carve(smem, T, N, c.obs_len, want_obs);
     const int tid = threadIdx.x;
     const int tile_base = blockIdx.x * T;
+    const int shift = want_obs ? (int)(((uintptr_t)a.out.d_obs + (size_t)tile_base * N * c.obs_len) & 15) : 0;
+    const Tile t = carve(smem, T, N, c.obs_len, want_obs, shift);
     const int tv = min(T, E - tile_base);
     const int cells = c.W * c.L;
     const int wave = tid / kWave, lane = tid % kWave;
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
     const int step_waves = (T + kWave - 1) / kWave;
 
     if (wave >= step_waves) {
-        if (want_obs) zero_tile(t, (int)(align16((size_t)tv * N * c.obs_len) >> 4), tid - step_waves * kWave,
+        if (want_obs) zero_tile(smem, (int)(align16((size_t)shift + (size_t)tv * N * c.obs_len) >> 4), tid - step_waves * kWave,
                                 kBlock - step_waves * kWave);
     } else {
         const int slot = tid;
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
     if (!want_obs) return;
     scatter_tile<N>(c, p, t, tile_base, tv, tid, kBlock);
     __syncthreads();
-    copy_tile_out(t, a.out.d_obs, (size_t)tile_base * N * c.obs_len, tv * N * c.obs_len, tid, kBlock);
+    copy_tile_out(t, shift, a.out.d_obs, (size_t)tile_base * N * c.obs_len, tv * N * c.obs_len, tid, kBlock);
 }
 
 // ---- standalone observation kernel (getObs after reset/restart/set_task, and the second launch of the
@@ -663,9 +669,10 @@ template <int N>
 __global__ __launch_bounds__(kBlock) void k_observe(DevCfg c, DevPtrs p, const uint8_t *mask, int8_t *gobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = c.T_obs, E = c.E;
-    const Tile t = carve(smem, T, N, c.obs_len, true);
     const int tid = threadIdx.x;
     const int tile_base = blockIdx.x * T;
+    const int shift = (int)(((uintptr_t)gobs + (size_t)tile_base * N * c.obs_len) & 15);
+    const Tile t = carve(smem, T, N, c.obs_len, true, shift);
     const int tv = min(T, E - tile_base);
     constexpr int NP = Rec<N>::NP;
     bool all = true, any = true;
@@ -686,13 +693,13 @@ __global__ __launch_bounds__(kBlock) void k_observe(DevCfg c, DevPtrs p, const u
             t.goal[s * N + 2 * w + 1] = (uint16_t)(gw >> 16);
         }
     }
-    zero_tile(t, (int)(align16((size_t)tv * N * c.obs_len) >> 4), tid, kBlock);
+    zero_tile(smem, (int)(align16((size_t)shift + (size_t)tv * N * c.obs_len) >> 4), tid, kBlock);
     __syncthreads();
     scatter_tile<N>(c, p, t, tile_base, tv, tid, kBlock);
     __syncthreads();
     const int row_bytes = N * c.obs_len;
     if (all) {
-        copy_tile_out(t, gobs, (size_t)tile_base * row_bytes, tv * row_bytes, tid, kBlock);
+        copy_tile_out(t, shift, gobs, (size_t)tile_base * row_bytes, tv * row_bytes, tid, kBlock);
     } else {
         for (int s = 0; s < tv; ++s)
             if (mask[tile_base + s])

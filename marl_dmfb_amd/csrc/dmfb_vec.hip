@@ -154,18 +154,19 @@ struct dmfb_vec {
     int T_fused = 16;    // chips per workgroup of the fused step+observe launch (<= 64)
     int T_obs = 16;      // chips per workgroup of k_observe
     int split_min = 0;   // batches of at least this many chips use the step-only + observe pair
+    int T_min = 16;      // smallest tile pick_tile may choose (DMFB_VEC_MIN_TILE); smaller tiles do not pay off (measured)
 };
 
 namespace {
 
-// Tile of the LDS-staged observation: a multiple of 16 chips (keeps every tile's obs offset
-// 16-byte aligned), at most 64, obs block <= 40 KB so that >= 3-4 workgroups share a CU's 160 KiB,
-// and shrunk while the grid would not cover the 256 CUs a few times over.
+// Tile of the LDS-staged observation: at most 64 chips (wave 0 owns one chip per lane in the fused launch),
+// obs block <= 40 KB so that >= 3-4 workgroups share a CU's 160 KiB, and halved while the grid would not
+// cover the 256 CUs `min_groups`/256 times over (any tile size works: the tile is phase-aligned in LDS).
 int pick_tile(const dmfb_vec *h, int min_groups) {
     const int row = h->cfg.n_agents * h->dc.obs_len;
     int T = 64;
-    while (T > 16 && (size_t)T * row > 40 * 1024) T -= 16;
-    while (T > 16 && (h->cfg.n_envs + T - 1) / T < min_groups) T -= 16;
+    while (T > 1 && (size_t)T * row > 40 * 1024) T >>= 1;
+    while (T > h->T_min && (h->cfg.n_envs + T - 1) / T < min_groups) T >>= 1;
     return T;
 }
 
@@ -303,6 +304,7 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
     h->dp.zoom = h->zoom_dev;
     CREATE_TRY(hipMemsetAsync(h->dp.st, 0, st_bytes, s));
     d.fov_magic = d.fov >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)d.fov - 1) / (uint64_t)d.fov) : 0u;
+    if (const char *v = getenv("DMFB_VEC_MIN_TILE")) h->T_min = atoi(v) > 0 ? atoi(v) : 1;  // tuning knob
     h->T_fused = pick_tile(h, 1024);
     h->T_obs = pick_tile(h, 2048);
     d.T = h->T_fused; d.T_obs = h->T_obs;
@@ -396,7 +398,6 @@ int dmfb_vec_get_blocks(const dmfb_vec *h, int32_t *d_blocks, int *nb_out, void 
 int dmfb_vec_step(dmfb_vec *h, const void *d_actions, const double *d_uniforms, const uint8_t *d_active,
                   uint32_t flags, const dmfb_vec_step_out *out, void *stream) {
     if (!h || !d_actions || !out) return DMFB_ERR_BAD_ARG;
-    if (out->d_obs && ((uintptr_t)out->d_obs & 15)) return DMFB_ERR_BAD_ARG;  // 16-byte stores
     DeviceGuard g(h->cfg.device);
     StepArgs a;
     a.actions = d_actions; a.uniforms = d_uniforms; a.active = d_active; a.flags = flags; a.out = *out;

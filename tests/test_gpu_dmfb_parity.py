@@ -189,3 +189,29 @@ def test_block_density_rule_matches_reference():
     v = _vec(width=10, length=10, n_agents=2, fov=5, n_blocks=6, n_envs=4)
     o = DmfbOracle(10, 10, 2, n_blocks=6, fov=5, n_envs=4)
     assert v.get_blocks().shape[1] == 0 and o.get_blocks().shape[1] == 0
+
+
+def test_unaligned_obs_buffer_and_tiny_tiles(monkeypatch):
+    """The obs tile is phase-aligned in LDS to its HBM destination, so any tile size and any (even odd)
+    destination address must give the same bytes."""
+    from marl_dmfb_amd.env.dmfb import VecDMFB
+    ref = None
+    for tile in ('1', '2', '4', '16', '64'):
+        monkeypatch.setenv('DMFB_VEC_MIN_TILE', tile)
+        v = VecDMFB(n_envs=333, seed=77, **D)
+        v.reset()
+        n, L = D['n_agents'], v.obs_len
+        big = torch.zeros(333 * n * L + 64, dtype=torch.int8, device='cuda')
+        for off in (0, 3, 8, 13):
+            view = big[off:off + 333 * n * L].view(333, n, L)
+            v.observe(obs=view)
+            got = view.cpu().numpy().copy()
+            if ref is None:
+                ref = got
+            np.testing.assert_array_equal(got, ref, err_msg='tile %s offset %d' % (tile, off))
+        a = torch.randint(0, 5, (333, n), device='cuda')
+        v.step(a, autoreset=True)          # fused launch with the same tile
+        torch.cuda.synchronize()
+    o = DmfbOracle(n_envs=333, seed=77, **D)
+    o.reset()
+    np.testing.assert_array_equal(ref, o.observe())
