@@ -165,7 +165,9 @@ namespace {
 int pick_tile(const dmfb_vec *h, int min_groups) {
     const int row = h->cfg.n_agents * h->dc.obs_len;
     int T = 64;
-    while (T > 1 && (size_t)T * row > 40 * 1024) T >>= 1;
+    size_t cap = 40 * 1024;
+    if (const char *v = getenv("DMFB_VEC_TILE_KB")) cap = (size_t)atoi(v) * 1024;  // tuning knob
+    while (T > 1 && (size_t)T * row > cap) T >>= 1;
     while (T > h->T_min && (h->cfg.n_envs + T - 1) / T < min_groups) T >>= 1;
     return T;
 }

@@ -366,7 +366,9 @@ int meda_vec_create(const meda_vec_config *cfg, void *stream, meda_vec **out) {
     d.per_healthy = 1.0 - cfg->per_degrade;
     const int E = cfg->n_envs, n = cfg->n_agents;
     const size_t row = (size_t)n * d.obs_len;
-    int T = (int)((40 * 1024) / row);
+    size_t cap = 40 * 1024;
+    if (const char *v = getenv("MEDA_VEC_TILE_KB")) cap = (size_t)atoi(v) * 1024;  // tuning knob
+    int T = (int)(cap / row);
     if (T < 1) T = 1;
     if (T > 32) T = 32;
     while (T > 1 && (E + T - 1) / T < 512) --T;  // keep the grid wide for small batches

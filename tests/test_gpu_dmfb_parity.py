@@ -215,3 +215,36 @@ def test_unaligned_obs_buffer_and_tiny_tiles(monkeypatch):
     o = DmfbOracle(n_envs=333, seed=77, **D)
     o.reset()
     np.testing.assert_array_equal(ref, o.observe())
+
+
+def test_reset_new_and_masked_restart():
+    """reset(new=True) re-initialises the maps and draws a NEW degradation map (dmfb.py:178-181);
+    restart(mask) puts the masked chips back on their starts (dmfb.py:599-605)."""
+    rng = np.random.default_rng(9)
+    O = DmfbOracle(n_envs=24, seed=5, **Ecfg)
+    V = _vec(n_envs=24, seed=5, **Ecfg)
+    d0 = V.get_map('degrade')
+    np.testing.assert_array_equal(_bits(O.get_map('degrade')), _bits(d0))
+    h = rng.random((24, 20, 20)) * 0.5 + 0.5
+    for B in (O, V):
+        B.set_map('health', h)
+        B.set_map('usage', np.full((24, 20, 20), 60.0))
+        B.reset(new=True)
+    for m in ('health', 'usage', 'degrade'):
+        np.testing.assert_array_equal(_bits(O.get_map(m)), _bits(V.get_map(m)), err_msg=m)
+    assert np.all(V.get_map('health') == 1.0) and np.all(V.get_map('usage') == 0.0)
+    assert not np.array_equal(V.get_map('degrade'), d0)
+    for a, b in zip(O.get_task(), V.get_task()):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(O.observe(), V.observe())
+    for t in range(12):
+        a = rng.integers(0, 5, (24, 10)).astype(np.int32)
+        O.step(a); V.step(a)
+    mask = (rng.random(24) < 0.5).astype(np.uint8)
+    O.restart(mask=mask); V.restart(mask=mask)
+    so, sv = O.get_state(), V.get_state()
+    for k in ('pos', 'dist', 'step_count', 'constraints'):
+        np.testing.assert_array_equal(so[k], sv[k], err_msg=k)
+    np.testing.assert_array_equal(O.observe(), V.observe())
+    starts, _ = V.get_task()
+    np.testing.assert_array_equal(sv['pos'][mask == 1], starts[mask == 1])
