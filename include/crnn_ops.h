@@ -55,6 +55,22 @@ int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, c
                         float *d_part, int n_part, float *d_grads, void *stream);
 int crnn_last_hip_error(void);
 
+/* ---- GRU cell unrolled over an episode (network/base_net.py:56,69 nn.GRUCell; policy/vdn.py:174-191 time loop) ----
+ * One launch runs all T steps of h_t = GRUCell(x_t, h_{t-1}) for R independent rows (hidden must be 128):
+ *   d_igates float32[T][R][3H] = x_t @ W_ih^T WITHOUT bias (one GEMM over all steps, done by the caller)
+ *   d_h0     float32[R][H]       d_w_hh float32[3H][H]   d_b_ih, d_b_hh float32[3H]   gate order r|z|n
+ *   d_hs     float32[T][R][H]    every h_t
+ *   d_gates  float32[T][R][4H]   saved r | z | n | (W_hn h + b_hn) for the backward; NULL for inference */
+int gru_seq_forward(const float *d_igates, const float *d_h0, const float *d_w_hh, const float *d_b_ih, const float *d_b_hh,
+                    int T, int64_t R, int hidden, float *d_hs, float *d_gates, void *stream);
+/* Backward through time of the above: d_grad_hs float32[T][R][H] = dL/dh_t from the consumers of each step.
+ * Writes d_d_igates float32[T][R][3H] (gradient w.r.t. d_igates = w.r.t. the pre-activations on the input side, so
+ * db_ih is its column sum) and d_d_hgates float32[T][R][3H] (w.r.t. W_hh h + b_hh: dW_hh = d_hgates^T @ h_{t-1}
+ * stacked over t, db_hh its column sum), optionally d_d_h0 float32[R][H]. */
+int gru_seq_backward(const float *d_grad_hs, const float *d_gates, const float *d_hs, const float *d_h0, const float *d_w_hh,
+                     int T, int64_t R, int hidden, float *d_d_igates, float *d_d_hgates, float *d_d_h0, void *stream);
+int gru_last_hip_error(void);
+
 #ifdef __cplusplus
 }
 #endif

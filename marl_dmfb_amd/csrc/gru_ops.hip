@@ -1,0 +1,213 @@
+// gru_ops.hip -- the GRU cell of the reference's Q-network (network/base_net.py:56,69: nn.GRUCell(.., 128))
+// unrolled over a whole episode inside ONE kernel launch, forward and backward, for gfx950.
+//
+// Why: VDN.learn unrolls the cell over T = 40..200 time steps (policy/vdn.py:174-191).  Through library
+// calls every step is a chain of 3-8 launches of a few microseconds each on a (B*n) x 128 state -- latency,
+// not work.  The recurrence is independent per row, so a workgroup can own a block of rows for the whole
+// sequence and keep everything it needs on chip:
+//   * W_hh (3H x H = 196 KB fp32) does not fit LDS; it is spread over the REGISTERS of the 512 threads:
+//     thread (q, u) holds the 3 gate rows of hidden unit u restricted to the k-range [32q, 32q+32) (96 floats);
+//   * h of the workgroup's RW rows lives in LDS; per step every thread forms its 3 partial dot products per
+//     row from 16-byte broadcast LDS reads, the 4 k-quarters are reduced through LDS, then thread (q, u)
+//     finishes the gates of rows 2q, 2q+1;
+//   * the backward pass walks t = T-1..0 with the transposed register layout (thread (q, j) holds
+//     W_hh[g*H + 32q + k][j]) for dh_{t-1} += W_hh^T d_hgates.
+// The input projection x @ W_ih^T (all steps at once) and the weight gradients (from the stacked gate
+// gradients) stay large rocBLAS GEMMs outside.  fp32, same formulas as torch's fused GRU cell:
+//   r = s(i_r+b_ir+h_r+b_hr)  z = s(i_z+b_iz+h_z+b_hz)  n = tanh(i_n+b_in + r*(h_n+b_hn))  h' = (1-z)*n + z*h
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/crnn_ops.h"
+
+namespace {
+
+constexpr int kBlock = 512;
+constexpr int H = 128;   // rnn_hidden_dim of every shipped config
+constexpr int RW = 8;    // rows per workgroup: thread (q, u) finishes rows 2q and 2q+1
+constexpr int KQ = 32;   // k-range per thread
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__global__ __launch_bounds__(kBlock) void k_gru_seq_fwd(const float *__restrict__ igates, const float *__restrict__ h0,
+                                                        const float *__restrict__ w_hh, const float *__restrict__ b_ih,
+                                                        const float *__restrict__ b_hh, int T, long R,
+                                                        float *__restrict__ hs, float *__restrict__ gates) {
+    __shared__ __attribute__((aligned(16))) float s_h[RW][H];
+    __shared__ __attribute__((aligned(16))) float s_part[4][RW][3][H];
+    const int tid = threadIdx.x, q = tid / H, u = tid - q * H;
+    const long row0 = (long)blockIdx.x * RW;
+    const int rv = (int)min((long)RW, R - row0);
+    float w[3][KQ];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) w[g][k] = w_hh[(size_t)(g * H + u) * H + q * KQ + k];
+    const float bir = b_ih[u] + b_hh[u], biz = b_ih[H + u] + b_hh[H + u], bin = b_ih[2 * H + u], bhn = b_hh[2 * H + u];
+    for (int i = tid; i < RW * H; i += kBlock) {
+        const int rr = i / H, c = i - rr * H;
+        s_h[rr][c] = rr < rv ? h0[(row0 + rr) * H + c] : 0.0f;
+    }
+    __syncthreads();
+    const int ra = 2 * q;  // this thread finishes rows ra and ra + 1
+    for (int t = 0; t < T; ++t) {
+        // input gates of my two rows (independent of the recurrence: issued first, consumed after the reduction)
+        float ig[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int rr = ra + s;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) ig[s][g] = rr < rv ? igates[((size_t)t * R + row0 + rr) * 3 * H + g * H + u] : 0.0f;
+        }
+        // partial h @ W_hh^T over my k-quarter, all RW rows
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            float hc[KQ];
+            const float4 *ph = (const float4 *)(&s_h[rr][q * KQ]);
+#pragma unroll
+            for (int j = 0; j < KQ / 4; ++j) { const float4 v = ph[j]; hc[4 * j] = v.x; hc[4 * j + 1] = v.y; hc[4 * j + 2] = v.z; hc[4 * j + 3] = v.w; }
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) acc = fmaf(w[g][k], hc[k], acc);
+                s_part[q][rr][g][u] = acc;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int rr = ra + s;
+            if (rr < rv) {
+                const float hr = s_part[0][rr][0][u] + s_part[1][rr][0][u] + s_part[2][rr][0][u] + s_part[3][rr][0][u];
+                const float hz = s_part[0][rr][1][u] + s_part[1][rr][1][u] + s_part[2][rr][1][u] + s_part[3][rr][1][u];
+                const float hn = s_part[0][rr][2][u] + s_part[1][rr][2][u] + s_part[2][rr][2][u] + s_part[3][rr][2][u] + bhn;
+                const float rg = sigmoidf_(ig[s][0] + hr + bir);
+                const float zg = sigmoidf_(ig[s][1] + hz + biz);
+                const float ng = tanhf(ig[s][2] + bin + rg * hn);
+                const float hp = s_h[rr][u];
+                const float hnew = (1.0f - zg) * ng + zg * hp;
+                const size_t o = ((size_t)t * R + row0 + rr);
+                hs[o * H + u] = hnew;
+                if (gates) {
+                    gates[o * 4 * H + u] = rg; gates[o * 4 * H + H + u] = zg; gates[o * 4 * H + 2 * H + u] = ng;
+                    gates[o * 4 * H + 3 * H + u] = hn;
+                }
+                s_h[rr][u] = hnew;  // only this thread reads s_h[rr][u] between the two barriers
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict__ grad_hs, const float *__restrict__ gates,
+                                                        const float *__restrict__ hs, const float *__restrict__ h0,
+                                                        const float *__restrict__ w_hh, int T, long R,
+                                                        float *__restrict__ d_ig, float *__restrict__ d_hg,
+                                                        float *__restrict__ d_h0) {
+    __shared__ __attribute__((aligned(16))) float s_dhg[RW][3][H];
+    __shared__ __attribute__((aligned(16))) float s_part[4][RW][H];
+    const int tid = threadIdx.x, q = tid / H, u = tid - q * H;
+    const long row0 = (long)blockIdx.x * RW;
+    const int rv = (int)min((long)RW, R - row0);
+    float wt[3][KQ];  // W_hh[g*H + 32q + k][u]: column u of the rows of my k-quarter
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) wt[g][k] = w_hh[(size_t)(g * H + q * KQ + k) * H + u];
+    const int ra = 2 * q;
+    float gh[2] = {0.0f, 0.0f};  // dL/dh_t arriving from the future for my two (row, u) entries
+    for (int t = T - 1; t >= 0; --t) {
+        float direct[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int rr = ra + s;
+            float dpr = 0.0f, dpz = 0.0f, dpn = 0.0f, dhn = 0.0f;
+            direct[s] = 0.0f;
+            if (rr < rv) {
+                const size_t o = ((size_t)t * R + row0 + rr);
+                const float g = grad_hs[o * H + u] + gh[s];
+                const float rg = gates[o * 4 * H + u], zg = gates[o * 4 * H + H + u], ng = gates[o * 4 * H + 2 * H + u],
+                            hn = gates[o * 4 * H + 3 * H + u];
+                const float hp = t > 0 ? hs[(o - R) * H + u] : h0[(row0 + rr) * H + u];
+                const float dn = g * (1.0f - zg), dz = g * (hp - ng);
+                direct[s] = g * zg;
+                dpn = dn * (1.0f - ng * ng);
+                dhn = dpn * rg;
+                dpr = dpn * hn * rg * (1.0f - rg);
+                dpz = dz * zg * (1.0f - zg);
+                d_ig[o * 3 * H + u] = dpr; d_ig[o * 3 * H + H + u] = dpz; d_ig[o * 3 * H + 2 * H + u] = dpn;
+                d_hg[o * 3 * H + u] = dpr; d_hg[o * 3 * H + H + u] = dpz; d_hg[o * 3 * H + 2 * H + u] = dhn;
+            }
+            s_dhg[rr][0][u] = dpr; s_dhg[rr][1][u] = dpz; s_dhg[rr][2][u] = dhn;
+        }
+        __syncthreads();
+        // partial W_hh^T d_hgates over my k-quarter of the gate rows, output column u, all RW rows
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const float4 *pd = (const float4 *)(&s_dhg[rr][g][q * KQ]);
+#pragma unroll
+                for (int j = 0; j < KQ / 4; ++j) {
+                    const float4 v = pd[j];
+                    acc = fmaf(wt[g][4 * j], v.x, acc); acc = fmaf(wt[g][4 * j + 1], v.y, acc);
+                    acc = fmaf(wt[g][4 * j + 2], v.z, acc); acc = fmaf(wt[g][4 * j + 3], v.w, acc);
+                }
+            }
+            s_part[q][rr][u] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int rr = ra + s;
+            gh[s] = direct[s] + s_part[0][rr][u] + s_part[1][rr][u] + s_part[2][rr][u] + s_part[3][rr][u];
+        }
+        // the next iteration writes s_dhg only after its first barrier's predecessor: all reads of s_dhg above are
+        // complete (second barrier), and s_part is rewritten only after the next first barrier
+    }
+    if (d_h0)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (ra + s < rv) d_h0[(row0 + ra + s) * H + u] = gh[s];
+}
+
+thread_local int g_last = 0;
+
+}  // namespace
+
+extern "C" {
+
+int gru_seq_forward(const float *d_igates, const float *d_h0, const float *d_w_hh, const float *d_b_ih, const float *d_b_hh,
+                    int T, int64_t R, int hidden, float *d_hs, float *d_gates, void *stream) {
+    if (!d_igates || !d_h0 || !d_w_hh || !d_b_ih || !d_b_hh || !d_hs || T < 0 || R < 0) return CRNN_ERR_BAD_ARG;
+    if (hidden != H) return CRNN_ERR_UNSUPPORTED;
+    if (T == 0 || R == 0) return CRNN_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_gru_seq_fwd, dim3((unsigned)((R + RW - 1) / RW)), dim3(kBlock), 0, (hipStream_t)stream, d_igates, d_h0, d_w_hh,
+                       d_b_ih, d_b_hh, T, (long)R, d_hs, d_gates);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last = (int)e; return CRNN_ERR_HIP; }
+    return CRNN_OK;
+}
+
+int gru_seq_backward(const float *d_grad_hs, const float *d_gates, const float *d_hs, const float *d_h0, const float *d_w_hh,
+                     int T, int64_t R, int hidden, float *d_d_igates, float *d_d_hgates, float *d_d_h0, void *stream) {
+    if (!d_grad_hs || !d_gates || !d_hs || !d_h0 || !d_w_hh || !d_d_igates || !d_d_hgates || T < 0 || R < 0) return CRNN_ERR_BAD_ARG;
+    if (hidden != H) return CRNN_ERR_UNSUPPORTED;
+    if (T == 0 || R == 0) return CRNN_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_gru_seq_bwd, dim3((unsigned)((R + RW - 1) / RW)), dim3(kBlock), 0, (hipStream_t)stream, d_grad_hs, d_gates, d_hs,
+                       d_h0, d_w_hh, T, (long)R, d_d_igates, d_d_hgates, d_d_h0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last = (int)e; return CRNN_ERR_HIP; }
+    return CRNN_OK;
+}
+
+int gru_last_hip_error(void) { return g_last; }
+
+}  // extern "C"

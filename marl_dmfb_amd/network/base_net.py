@@ -137,6 +137,71 @@ class _GRUSeq(torch.autograd.Function):
         return d_ig, gh, d_w_hh, d_ig.sum(dim=(0, 1)), d_hg.sum(dim=(0, 1))
 
 
+class _GRUSeqHip(torch.autograd.Function):
+    """The same node as `_GRUSeq`, but the whole time loop is ONE launch each way (include/crnn_ops.h
+    gru_seq_forward / gru_seq_backward, csrc/gru_ops.hip): W_hh lives in registers, h in LDS, a workgroup
+    owns 8 rows for all T steps.  Hidden size 128 only (every shipped config)."""
+
+    @staticmethod
+    def _lib():
+        from .. import _lib
+        return _lib.crnn_ops()
+
+    @staticmethod
+    def run_forward(igates, h0, w_hh, b_ih, b_hh, save):
+        import ctypes as C
+        lib = _GRUSeqHip._lib()
+        T, R, G = igates.shape
+        H = G // 3
+        igates, h0, w_hh = igates.contiguous(), h0.contiguous(), w_hh.contiguous()
+        hs = torch.empty((T, R, H), dtype=torch.float32, device=igates.device)
+        gates = torch.empty((T, R, 4 * H), dtype=torch.float32, device=igates.device) if save else None
+        vp = C.c_void_p
+        rc = lib.gru_seq_forward(vp(igates.data_ptr()), vp(h0.data_ptr()), vp(w_hh.data_ptr()), vp(b_ih.data_ptr()),
+                                 vp(b_hh.data_ptr()), T, R, H, vp(hs.data_ptr()),
+                                 vp(gates.data_ptr()) if save else None,
+                                 vp(torch.cuda.current_stream(igates.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('gru_seq_forward failed: %d (hip %d)' % (rc, lib.gru_last_hip_error()))
+        return hs, gates
+
+    @staticmethod
+    def forward(ctx, igates, h0, w_hh, b_ih, b_hh):
+        hs, gates = _GRUSeqHip.run_forward(igates.detach(), h0.detach(), w_hh.detach(), b_ih.detach(), b_hh.detach(), True)
+        ctx.save_for_backward(hs, gates, h0, w_hh)
+        return hs
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        import ctypes as C
+        hs, gates, h0, w_hh = ctx.saved_tensors
+        lib = _GRUSeqHip._lib()
+        T, R, H = hs.shape
+        grad_out = grad_out.contiguous()
+        h0c, w = h0.contiguous(), w_hh.contiguous()
+        d_ig = torch.empty((T, R, 3 * H), dtype=torch.float32, device=hs.device)
+        d_hg = torch.empty_like(d_ig)
+        d_h0 = torch.empty_like(h0c)
+        vp = C.c_void_p
+        rc = lib.gru_seq_backward(vp(grad_out.data_ptr()), vp(gates.data_ptr()), vp(hs.data_ptr()), vp(h0c.data_ptr()),
+                                  vp(w.data_ptr()), T, R, H, vp(d_ig.data_ptr()), vp(d_hg.data_ptr()), vp(d_h0.data_ptr()),
+                                  vp(torch.cuda.current_stream(hs.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('gru_seq_backward failed: %d (hip %d)' % (rc, lib.gru_last_hip_error()))
+        h_prev = torch.cat([h0c.unsqueeze(0), hs[:-1]], dim=0)
+        d_w_hh = torch.matmul(d_hg.view(T * R, 3 * H).t(), h_prev.view(T * R, H))
+        return d_ig, d_h0, d_w_hh, d_ig.sum(dim=(0, 1)), d_hg.sum(dim=(0, 1))
+
+
+def gru_sequence(igates, h0, w_hh, b_ih, b_hh, impl='hip'):
+    """hs (T, R, H) of the GRU recurrence given the input-side pre-activations of all steps."""
+    if impl == 'hip' and h0.shape[-1] == 128 and igates.dtype == torch.float32:
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (igates, h0, w_hh, b_ih, b_hh)):
+            return _GRUSeqHip.apply(igates, h0, w_hh, b_ih, b_hh)
+        return _GRUSeqHip.run_forward(igates, h0, w_hh, b_ih, b_hh, False)[0]
+    return _GRUSeq.apply(igates, h0, w_hh, b_ih, b_hh)
+
+
 def conv_str(fov, id=3, od=32):
     stack, shared = [], None
     for from_image, stride in _CONV_PLAN[fov]:
@@ -208,15 +273,16 @@ class CRNN(nn.Module):
     def recurrent_seq(self, x_seq, h0):
         """GRU cell + head over a whole sequence x_seq (T, R, F) from h0 (R, H): returns (q (T, R, A), h_T).
         On the GPU the input projection x @ W_ih^T of ALL steps is one GEMM and the head runs once
-        over the stacked hidden states; per step only h @ W_hh^T and the fused gate kernel remain
-        (the same `_thnn_fused_gru_cell` nn.GRUCell dispatches to, so the arithmetic per step is
-        GRUCell's)."""
+        over the stacked hidden states; the recurrence itself is one HIP launch for all T steps
+        (`_GRUSeqHip`, hidden 128; `gru_impl='aten'` selects the per-step `_thnn_fused_gru_cell` path,
+        the kernel nn.GRUCell dispatches to)."""
         T, R = x_seq.shape[0], x_seq.shape[1]
         h = h0.reshape(-1, self.rnn_hidden_dim)
         hs = []
         if x_seq.is_cuda:
             igates = torch.matmul(x_seq.reshape(T * R, -1), self.rnn.weight_ih.t()).view(T, R, -1)
-            hseq = _GRUSeq.apply(igates, h, self.rnn.weight_hh, self.rnn.bias_ih, self.rnn.bias_hh)
+            hseq = gru_sequence(igates, h, self.rnn.weight_hh, self.rnn.bias_ih, self.rnn.bias_hh,
+                                getattr(self, 'gru_impl', 'hip'))
             q = self.fc1(hseq.view(T * R, -1)).view(T, R, -1)
             return q, hseq[-1]
         else:

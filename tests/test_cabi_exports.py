@@ -86,7 +86,10 @@ def test_crnn_ops_library_exports():
     names = sorted(set(re.findall(r'\b(crnn_[a-z_0-9]+)\s*\(', txt)))
     assert names == ['crnn_conv9_a1_floats', 'crnn_conv9_backward', 'crnn_conv9_backward_parts', 'crnn_conv9_forward', 'crnn_conv9_forward_train',
                      'crnn_front9_forward', 'crnn_last_hip_error']
-    for n in names:
+    gru = sorted(set(re.findall(r'\b(gru_[a-z_0-9]+)\s*\(', txt)))
+    assert gru == ['gru_last_hip_error', 'gru_seq_backward', 'gru_seq_forward']
+    for n in names + gru:
         assert hasattr(lib, n)
     # argument guards run on the host before anything touches the GPU
     assert lib.crnn_conv9_forward(None, 245, 4, None, None, None, None, 24, None, 600, None) == -1
+    assert lib.gru_seq_forward(None, None, None, None, None, 4, 8, 128, None, None, None) == -1

@@ -76,3 +76,60 @@ def test_conv9_training_pair_matches_torch_autograd(od, rows):
         g = g.numpy()
         assert np.linalg.norm(g - r) <= 2e-3 * np.linalg.norm(r)
         assert np.abs(g - r).max() <= 1e-2 * np.abs(r).max()
+
+
+@pytest.mark.parametrize('T,R', [(1, 1), (5, 13), (40, 2048), (17, 520)])
+def test_gru_sequence_kernels_match_grucell_autograd(T, R):
+    """gru_seq_forward / gru_seq_backward (one launch for all T steps) against nn.GRUCell unrolled in float64 on the
+    CPU (network/base_net.py:56,69; policy/vdn.py:174-191).  fp32 tolerance: 2e-5 absolute on h (|h| <= 1),
+    relative L2 2e-4 on every gradient."""
+    from marl_dmfb_amd.network.base_net import gru_sequence
+    torch.manual_seed(T * 1000 + R)
+    H, F = 128, 64
+    cell = torch.nn.GRUCell(F, H).cuda()
+    x = torch.randn(T, R, F, device='cuda', requires_grad=True)
+    h0 = (torch.rand(R, H, device='cuda') * 2 - 1).requires_grad_(True)
+    gout = torch.randn(T, R, H, device='cuda')
+    igates = torch.matmul(x.view(T * R, F), cell.weight_ih.t()).view(T, R, 3 * H)
+    hs = gru_sequence(igates, h0, cell.weight_hh, cell.bias_ih, cell.bias_hh, 'hip')
+    with torch.no_grad():
+        hs_ng = gru_sequence(igates.detach(), h0.detach(), cell.weight_hh, cell.bias_ih, cell.bias_hh, 'hip')
+    assert torch.equal(hs_ng, hs.detach())          # inference launch (no saved gates) == training launch
+    (hs * gout).sum().backward()
+    got = [t.grad.detach().cpu().double() for t in (x, h0, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)]
+    ref = torch.nn.GRUCell(F, H).double()
+    ref.load_state_dict({k: v.detach().double().cpu() for k, v in cell.state_dict().items()})
+    xr = x.detach().double().cpu().requires_grad_(True)
+    hr0 = h0.detach().double().cpu().requires_grad_(True)
+    h, outs = hr0, []
+    for t in range(T):
+        h = ref(xr[t], h)
+        outs.append(h)
+    hr = torch.stack(outs, 0)
+    np.testing.assert_allclose(hs.detach().cpu().numpy(), hr.detach().numpy(), rtol=0, atol=2e-5)
+    (hr * gout.double().cpu()).sum().backward()
+    for g, r in zip(got, (xr.grad, hr0.grad, ref.weight_ih.grad, ref.weight_hh.grad, ref.bias_ih.grad, ref.bias_hh.grad)):
+        assert torch.linalg.norm(g - r) <= 2e-4 * torch.linalg.norm(r) + 1e-9
+
+
+def test_recurrent_seq_hip_equals_aten_path():
+    """CRNN.recurrent_seq through the one-launch GRU kernels vs the per-step aten fused cell: q values and the
+    gradients of a sum agree to fp32 rounding."""
+    from marl_dmfb_amd.network.base_net import CRNN
+    a = types.SimpleNamespace(obs_shape=(3, 9, 9, 2, 245), hyper_hidden_dim=24, rnn_hidden_dim=128, n_actions=5, fov=9)
+    torch.manual_seed(3)
+    net = CRNN(a).cuda()
+    T, R = 12, 300
+    x = torch.randn(T, R, net.out + 10, device='cuda')
+    h0 = torch.zeros(R, 128, device='cuda')
+    res = {}
+    for impl in ('hip', 'aten'):
+        net.gru_impl = impl
+        net.zero_grad()
+        q, hT = net.recurrent_seq(x, h0)
+        (q.square().sum() + hT.sum()).backward()
+        res[impl] = (q.detach().clone(), hT.detach().clone(), [p.grad.clone() for p in net.rnn.parameters()])
+    np.testing.assert_allclose(res['hip'][0].cpu().numpy(), res['aten'][0].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(res['hip'][1].cpu().numpy(), res['aten'][1].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    for g1, g2 in zip(res['hip'][2], res['aten'][2]):
+        assert torch.linalg.norm(g1 - g2) <= 1e-4 * torch.linalg.norm(g2)
