@@ -1,0 +1,260 @@
+// crnn_mfma.h -- the same conv1+ReLU+conv2+ReLU front end as k_conv9 (crnn_ops.hip), on the gfx950 matrix cores
+// with f32 operands: v_mfma_f32_16x16x4_f32 is an exact f32 fma chain at 64 FLOP/clk/SIMD, twice the rate of the
+// plain (non-packed) v_fma_f32 stream the VALU kernel issues.  Both convolutions are GEMMs whose M dimension is
+// (row, output position) flattened, N the output channel (two 16-wide halves; od 24 leaves 8 columns of the second
+// half idle) and K the (input channel, tap) pairs:
+//   conv1: M = RB*49, K = 27 (+1 zero), A gathered from the float image of the int8 pixel rows in LDS
+//   conv2: M = RB*25, K = od*9,          A gathered from the conv1 activations in LDS
+// The A operand of the 16x16x4 form is ONE float per lane (lane l: A[i = l & 15][k = l >> 4]) so the im2col gather
+// is a single ds_read_b32 per MFMA with a compile-time offset: K is ordered (channel quad, tap) with the lane's
+// k = l >> 4 selecting the channel inside the quad, which folds into the per-lane base address.  The B operands
+// (the weights of the lane's output channel) stay in registers for the whole kernel: 7 + od*9/4 VGPRs.
+// 8 waves per workgroup, two per SIMD; SIMDs 0,1 own channel half 0, SIMDs 2,3 half 1; each wave walks every fourth
+// 16-position tile of its half with two tiles (two independent accumulators) in flight.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace crnn_mfma {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBlockM = 512;
+
+template <int OD> struct GeoM {
+    static constexpr int RB = OD <= 24 ? 16 : 12;       // rows per iteration (LDS-bound)
+    static constexpr int CS = 53;                        // conv1 activation stride per channel: odd, so the epilogue's
+                                                         // 16 channel lanes fall on different banks
+    static constexpr int ROW_A1 = OD * CS;
+    static constexpr int IN_STRIDE = 244;
+    static constexpr int OUT_STRIDE = OD * 25 + 12;      // staged output row: conv features | 10 vector features | pad
+    static constexpr int KQ = OD / 4;                    // channel quads
+    static constexpr int NSTEP2 = KQ * 9;                // conv2 k-steps (54 / 72)
+    static constexpr int M1 = RB * 49, M2 = RB * 25;
+    static constexpr int T2 = (M2 + 15) / 16;
+    static_assert(RB % 4 == 0 && RB <= 16, "conv1 tiling: rows split over 4 waves per half, one position-48 tile");
+    static constexpr int VEC = 18;                       // dir_x, dir_y, one-hot (<= 16) per row
+    static constexpr int NPF = (RB * 243 + kBlockM - 1) / kBlockM;  // pixel bytes prefetched per thread
+    static constexpr size_t LDS_FLOATS = (size_t)RB * IN_STRIDE + (size_t)RB * ROW_A1 + (size_t)RB * OUT_STRIDE + (size_t)RB * VEC;
+};
+
+// conv2 for NT (1 or 2) tiles of 16 output positions: gathers of channel quad cq + 1 are issued before the MFMAs of
+// quad cq (sched_barrier keeps that order), so an LDS read has a whole quad of MFMA issue time to land.
+template <int OD, int NT>
+__device__ __forceinline__ void conv2_tiles(const float *s_a1, float *s_out, const float (&bw2)[GeoM<OD>::NSTEP2], float bias2,
+                                            int t0, int t1, int j, int kq, int ch, bool chv) {
+    using G = GeoM<OD>;
+    const float *ap[NT];
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        int m = (n == 0 ? t0 : t1) * 16 + j;
+        m = m < G::M2 ? m : G::M2 - 1;
+        const int r = m / 25, p = m - r * 25;
+        ap[n] = s_a1 + r * G::ROW_A1 + (p / 5) * 7 + p % 5 + kq * G::CS;
+        acc[n] = f32x4{bias2, bias2, bias2, bias2};
+    }
+    float v[2][NT][9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) v[0][n][tap] = ap[n][(tap / 3) * 7 + tap % 3];
+#pragma unroll
+    for (int cq = 0; cq < G::KQ; ++cq) {
+        if (cq + 1 < G::KQ) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    v[(cq + 1) & 1][n][tap] = ap[n][(cq + 1) * 4 * G::CS + (tap / 3) * 7 + tap % 3];  // compile-time offset:imm
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[cq & 1][n][tap], bw2[cq * 9 + tap], acc[n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (chv) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mm = (n == 0 ? t0 : t1) * 16 + kq * 4 + q;
+                if (mm < G::M2) { const int rr = mm / 25, pp = mm - rr * 25; s_out[rr * G::OUT_STRIDE + ch * 25 + pp] = fmaxf(acc[n][q], 0.0f); }
+            }
+    }
+}
+
+template <int OD>
+__global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict__ obs, long obs_stride, long rows,
+                                                        const float *__restrict__ w1, const float *__restrict__ b1,
+                                                        const float *__restrict__ w2, const float *__restrict__ b2,
+                                                        float *__restrict__ out, long out_stride,
+                                                        const int8_t *__restrict__ onehot, int n_actions,
+                                                        const float *__restrict__ mlp_w, const float *__restrict__ mlp_b,
+                                                        float *__restrict__ a1_save) {
+    using G = GeoM<OD>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *s_in = lds;                              // [RB][244]  float image of the pixel bytes
+    float *s_a1 = s_in + G::RB * G::IN_STRIDE;      // [RB][OD][53] conv1 activations
+    float *s_out = s_a1 + G::RB * G::ROW_A1;        // [RB][OUT_STRIDE]
+    float *s_vec = s_out + G::RB * G::OUT_STRIDE;   // [RB][18] inputs of the vector branch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave w runs on SIMD w & 3: SIMDs 0,1 hold channel half 0, SIMDs 2,3 half 1; the two waves of a SIMD take
+    // tiles sub, sub + 4, ... with sub = (w & 1) and (w & 1) + 2, so every SIMD gets 12 or 13 of the 25 conv2 tiles
+    const int nh = (wave >> 1) & 1, sub = (wave & 1) + 2 * (wave >> 2);
+    const int j = lane & 15, kq = lane >> 4;
+    const int ch = nh * 16 + j;                     // the output channel this lane's B column / D column belongs to
+    const bool chv = ch < OD;
+
+    // ---- B operands (weights of channel ch) and the lane's conv1 gather offsets
+    float bw1[7];
+    int off1[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int k = 4 * s + kq;
+        const bool kv = k < 27;
+        bw1[s] = (chv && kv) ? w1[ch * 27 + k] : 0.0f;
+        const int c0 = k / 9, tap = k - c0 * 9;
+        off1[s] = kv ? c0 * 81 + (tap / 3) * 9 + tap % 3 : 0;
+    }
+    int goff[3];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) { const int p = qt * 16 + j; goff[qt] = (p / 7) * 9 + p % 7; }
+    float bw2[G::NSTEP2];
+#pragma unroll
+    for (int cq = 0; cq < G::KQ; ++cq)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) bw2[cq * 9 + tap] = chv ? w2[((size_t)ch * OD + 4 * cq + kq) * 9 + tap] : 0.0f;
+    const float bias1 = chv ? b1[ch] : 0.0f, bias2 = chv ? b2[ch] : 0.0f;
+    const int n_feat = OD * 25 + (mlp_w ? 10 : 0);
+
+    const long n_blocks = (rows + G::RB - 1) / G::RB;
+    const int nin = 2 + n_actions;
+    // The bytes of block i+1 are fetched into registers while block i is in conv1 and parked in LDS once conv1 is
+    // done with s_in: the HBM latency of the int8 rows never sits between two barriers.
+    float pf[G::NPF], pfv = 0.0f;
+    auto fetch = [&](long b) {
+        const long r0 = b * G::RB;
+        const int rvb = b < n_blocks ? (int)min((long)G::RB, rows - r0) : 0;
+#pragma unroll
+        for (int u = 0; u < G::NPF; ++u) {
+            const int i = tid + u * kBlockM, rr = i / 243, p = i - rr * 243;
+            pf[u] = (i < G::RB * 243 && rr < rvb) ? (float)obs[(r0 + rr) * obs_stride + p] : 0.0f;  // rows past the end: finite zeros
+        }
+        if (mlp_w && tid < G::RB * G::VEC) {
+            const int rr = tid / G::VEC, k = tid - rr * G::VEC;
+            pfv = 0.0f;
+            if (rr < rvb) {
+                if (k < 2) pfv = (float)obs[(r0 + rr) * obs_stride + 243 + k];
+                else if (onehot && k < nin) pfv = (float)onehot[(r0 + rr) * n_actions + (k - 2)];
+            }
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int u = 0; u < G::NPF; ++u) {
+            const int i = tid + u * kBlockM, rr = i / 243, p = i - rr * 243;
+            if (i < G::RB * 243) s_in[rr * G::IN_STRIDE + p] = pf[u];
+        }
+        if (mlp_w && tid < G::RB * G::VEC) s_vec[tid] = pfv;
+    };
+    fetch(blockIdx.x);
+    park();
+    for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const long row0 = blk * G::RB;
+        const int rv = (int)min((long)G::RB, rows - row0);
+        __syncthreads();
+        fetch(blk + gridDim.x);
+        // ---- conv1
+#ifndef CRNN_PROBE_SKIP_CONV1
+        {
+            // Tiles follow the rows so that no index needs a division: a row's positions 0..47 are three tiles
+            // (quarter qt: p = 16 qt + i), position 48 of all RB rows is one more tile.  Wave `sub` takes rows
+            // sub, sub + 4, ...: three accumulator chains per row; the gathers of the next row are in flight while
+            // the MFMAs of the current one issue.  Addresses are per-lane constants + compile-time offsets.
+            float cv[2][3][7];
+#pragma unroll
+            for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+                for (int s = 0; s < 7; ++s) cv[0][qt][s] = s_in[sub * G::IN_STRIDE + goff[qt] + off1[s]];
+#pragma unroll
+            for (int i = 0; i < G::RB / 4; ++i) {
+                if (i + 1 < G::RB / 4) {
+#pragma unroll
+                    for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+                        for (int s = 0; s < 7; ++s)
+                            cv[(i + 1) & 1][qt][s] = s_in[(sub + 4 * (i + 1)) * G::IN_STRIDE + goff[qt] + off1[s]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 acc[3];
+#pragma unroll
+                for (int qt = 0; qt < 3; ++qt) acc[qt] = f32x4{bias1, bias1, bias1, bias1};
+#pragma unroll
+                for (int s = 0; s < 7; ++s)
+#pragma unroll
+                    for (int qt = 0; qt < 3; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i & 1][qt][s], bw1[s], acc[qt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (chv) {
+                    float *dst = s_a1 + (sub + 4 * i) * G::ROW_A1 + ch * G::CS + kq * 4;
+#pragma unroll
+                    for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dst[qt * 16 + q] = fmaxf(acc[qt][q], 0.0f);
+                }
+            }
+            if (sub == 0) {  // position 48 (x = y = 6) of every row: lane i gathers row i
+                const int rr = j < G::RB ? j : G::RB - 1;
+                f32x4 acc = {bias1, bias1, bias1, bias1};
+#pragma unroll
+                for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s_in[rr * G::IN_STRIDE + 60 + off1[s]], bw1[s], acc, 0, 0, 0);
+                if (chv) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (kq * 4 + q < G::RB) s_a1[(kq * 4 + q) * G::ROW_A1 + ch * G::CS + 48] = fmaxf(acc[q], 0.0f);
+                }
+            }
+        }
+#endif
+        __syncthreads();
+        float mv = 0.0f;  // vector branch: relu(mlp1([dir_x, dir_y, last-action one-hot])) (base_net.py:66)
+        const int mr = tid / 10, mc = tid - mr * 10;
+        if (mlp_w && tid < G::RB * 10) {
+            mv = mlp_b[mc];
+            for (int k = 0; k < nin; ++k) mv = fmaf(s_vec[mr * G::VEC + k], mlp_w[mc * nin + k], mv);
+        }
+        if (a1_save) {  // training: the backward kernel wants [row][channel][52] (crnn_conv9_a1_floats); a wave per (row, channel)
+            if (lane < 49)
+                for (int pc = wave; pc < rv * OD; pc += kBlockM / 64) {
+                    const int rr = pc / OD, c = pc - rr * OD;
+                    a1_save[((row0 + rr) * OD + c) * 52 + lane] = s_a1[rr * G::ROW_A1 + c * G::CS + lane];
+                }
+        }
+        // ---- conv2
+#ifndef CRNN_PROBE_SKIP_CONV2
+        {
+            int t = sub;
+            for (; t + 4 < G::T2; t += 8) conv2_tiles<OD, 2>(s_a1, s_out, bw2, bias2, t, t + 4, j, kq, ch, chv);
+            if (t < G::T2) conv2_tiles<OD, 1>(s_a1, s_out, bw2, bias2, t, t, j, kq, ch, chv);
+        }
+#endif
+        if (mlp_w && tid < G::RB * 10) s_out[mr * G::OUT_STRIDE + OD * 25 + mc] = fmaxf(mv, 0.0f);
+        __syncthreads();
+        park();  // s_in / s_vec were last read before this barrier
+        // ---- stream the staged rows out: a wave per row, consecutive lanes on consecutive floats
+#ifndef CRNN_PROBE_SKIP_OUT
+        for (int rr = wave; rr < rv; rr += kBlockM / 64) {
+            float *dst = out + (row0 + rr) * out_stride;
+            const float *src = s_out + rr * G::OUT_STRIDE;
+            for (int k = lane; k < n_feat; k += 64) dst[k] = src[k];
+        }
+#endif
+        // next iteration: s_a1 is rewritten after its first barrier, s_out after its second
+    }
+}
+
+}  // namespace crnn_mfma

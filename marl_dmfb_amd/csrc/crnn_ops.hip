@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "../../include/crnn_ops.h"
+#include "crnn_mfma.h"
 
 namespace {
 
@@ -369,23 +370,36 @@ __global__ void k_conv9_bwd_reduce(const float *__restrict__ part, int n_part, f
 
 thread_local int g_last_hip = 0;
 
+bool use_valu_conv() {  // CRNN_CONV_IMPL=valu selects the f32 VALU kernel (k_conv9); default: the f32 MFMA kernel
+    static const bool v = [] { const char *e = getenv("CRNN_CONV_IMPL"); return e && e[0] == 'v'; }();
+    return v;
+}
+
 template <int OD>
 int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w2,
            const float *b2, float *out, long out_stride, const int8_t *onehot, int n_actions, const float *mlp_w,
            const float *mlp_b, float *a1_save, hipStream_t s) {
     using G = Geo<OD>;
-    const size_t lds = G::LDS_FLOATS * sizeof(float);
+    using GM = crnn_mfma::GeoM<OD>;
+    const bool valu = use_valu_conv();
+    const size_t lds = (valu ? G::LDS_FLOATS : GM::LDS_FLOATS) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv9<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = valu ? hipFuncSetAttribute((const void *)k_conv9<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                            : hipFuncSetAttribute((const void *)crnn_mfma::k_conv9_mfma<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
         attr_set = true;
     }
-    const long n_blocks = (rows + G::RB - 1) / G::RB;
-    const int grid = (int)(n_blocks < 256 ? n_blocks : 256);  // persistent: one 8-wave workgroup per CU keeps the weights resident
+    const int rb = valu ? G::RB : GM::RB;
+    const long n_blocks = (rows + rb - 1) / rb;
+    const int grid = (int)(n_blocks < 256 ? n_blocks : 256);  // persistent: one workgroup per CU keeps the weights resident
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_conv9<OD>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, w1, b1, w2, b2, out, out_stride, onehot,
-                       n_actions, mlp_w, mlp_b, a1_save);
+    if (valu)
+        hipLaunchKernelGGL((k_conv9<OD>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, w1, b1, w2, b2, out, out_stride, onehot,
+                           n_actions, mlp_w, mlp_b, a1_save);
+    else
+        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, s, obs, obs_stride, rows, w1, b1, w2, b2,
+                           out, out_stride, onehot, n_actions, mlp_w, mlp_b, a1_save);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_last_hip = (int)e;

@@ -1,0 +1,38 @@
+// Standalone timing probe for k_conv9_mfma<24>: build variants with -DCRNN_PROBE_SKIP_* to see which phase costs what.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../marl_dmfb_amd/csrc/crnn_mfma.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+int main(int argc, char **argv) {
+    constexpr int OD = 24;
+    using G = crnn_mfma::GeoM<OD>;
+    const long rows = argc > 1 ? atol(argv[1]) : 81920;
+    int8_t *obs; float *w1, *b1, *w2, *b2, *out;
+    CK(hipMalloc(&obs, rows * 245)); CK(hipMalloc(&w1, OD * 27 * 4)); CK(hipMalloc(&b1, OD * 4));
+    CK(hipMalloc(&w2, OD * OD * 9 * 4)); CK(hipMalloc(&b2, OD * 4)); CK(hipMalloc(&out, rows * 600 * 4));
+    std::vector<int8_t> h(rows * 245); for (auto &v : h) v = rand() % 5;
+    CK(hipMemcpy(obs, h.data(), h.size(), hipMemcpyHostToDevice));
+    std::vector<float> hw(OD * OD * 9); for (auto &v : hw) v = (rand() % 2001 - 1000) * 1e-4f;
+    CK(hipMemcpy(w2, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(w1, hw.data(), OD * 27 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(b1, hw.data(), OD * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b2, hw.data(), OD * 4, hipMemcpyHostToDevice));
+    const size_t lds = G::LDS_FLOATS * 4;
+    CK(hipFuncSetAttribute((const void *)crnn_mfma::k_conv9_mfma<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long nb = (rows + G::RB - 1) / G::RB;
+    const int grid = nb < 256 ? nb : 256;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int it = 0; it < 3; ++it)
+        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L,
+                           (const int8_t *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int it = 0; it < 20; ++it)
+        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L,
+                           (const int8_t *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%s rows %ld: %.1f us/launch\n", argv[0], rows, ms * 1e3 / 20);
+    return 0;
+}
