@@ -34,6 +34,9 @@ class Evaluator:
         # launch cost that otherwise dominates a lock-step of a few thousand chips.
         self.use_graph = False
         self._graphs = {}
+        self._rollout_lib = None
+        # key of the epsilon-greedy Philox stream: the env seed, shifted per shard so that ranks draw different numbers
+        self.rng_seed = (int(getattr(env, 'seed', 0)) * 0x9E3779B97F4A7C15 + int(getattr(env, 'env_id0', 0)) + 0x600) & 0xFFFFFFFFFFFFFFFF
 
     def _new_round(self, new=False):
         obs = self.reset_fn() if self.reset_fn is not None else self.env.reset(new=new)
@@ -72,18 +75,40 @@ class Evaluator:
         g['graph'].replay()
         return g['out']
 
+    def _ops(self):
+        if self._rollout_lib is None:
+            from .. import _lib
+            self._rollout_lib = _lib.rollout_ops()
+            self._draw = torch.zeros(1, dtype=torch.int32, device=self.device)     # Philox draw counter (device side)
+            self._n_alive = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._rollout_lib
+
     @torch.no_grad()
     def _play(self, epsilon, evaluate, record):
-        """One episode on every chip.  Returns per-chip stats and (if record) the episode batch."""
+        """One episode on every chip.  Returns per-chip stats and (if record) the episode batch.
+        Per lock-step: Q-net forward, rollout_select_actions, the fused env transition, rollout_post_step
+        (include/rollout_ops.h) -- the episode tensors are written in place by those kernels."""
+        import ctypes as C
         E, n, A, T = self.n_envs, self.n_agents, self.n_actions, self.episode_limit
         dev = self.device
+        lib = self._ops()
+        vp = C.c_void_p
+        stream = vp(torch.cuda.current_stream(dev).cuda_stream)
         obs, hidden, last_action = self._new_round()
-        alive = torch.ones(E, dtype=torch.bool, device=dev)
+        alive = torch.ones(E, dtype=torch.uint8, device=dev)
         reward = torch.zeros(E, dtype=torch.float64, device=dev)
         steps = torch.zeros(E, dtype=torch.int64, device=dev)
         constraints = torch.zeros(E, dtype=torch.float64, device=dev)  # MEDA reports a float (sum of punishments)
         success = torch.zeros(E, dtype=torch.int64, device=dev)
+        actions = torch.empty((E, n), dtype=torch.int32, device=dev)
+        eps = torch.as_tensor(epsilon, dtype=torch.float32, device=dev).reshape(1).clone()
+        anneal = 0.0
+        if not evaluate and self.agents.args.epsilon_anneal_scale == 'step':
+            anneal = float(self.anneal_epsilon)
+        min_eps = float(getattr(self, 'min_epsilon', 0.0))
         ep = None
+        null = vp(None)
+        p_u = p_oh = p_r = p_pad = p_term = null
         if record:
             O = self.env.obs_len
             ep = {'o': torch.zeros((E, T, n, O), dtype=torch.int8, device=dev),
@@ -95,34 +120,38 @@ class Evaluator:
                   'u_onehot': torch.zeros((E, T, n, A), dtype=torch.int8, device=dev),
                   'padded': torch.ones((E, T, 1), dtype=torch.bool, device=dev),
                   'terminated': torch.ones((E, T, 1), dtype=torch.bool, device=dev)}
-        eps = epsilon
+            p_u, p_oh, p_r = vp(ep['u'].data_ptr()), vp(ep['u_onehot'].data_ptr()), vp(ep['r'].data_ptr())
+            p_pad, p_term = vp(ep['padded'].data_ptr()), vp(ep['terminated'].data_ptr())
+            ep['o'][:, 0] = obs
+        net = self.agents.policy.eval_rnn
+        t_played = 0
         for t in range(T):
-            actions, hidden = self.agents.choose_actions(obs, last_action, hidden, eps, evaluate=evaluate,
-                                                         generator=self.generator)
-            onehot = torch.nn.functional.one_hot(actions, A).to(torch.int8)
-            if record:
-                ep['o'][:, t] = obs  # rows of frozen chips are zeroed in one pass after the loop
+            q, hidden = net.forward_obs(obs.reshape(E * n, -1), last_action.reshape(E * n, -1), hidden)
+            q = q.contiguous()
+            rc = lib.rollout_select_actions(vp(q.data_ptr()), E, n, A, vp(eps.data_ptr()), int(bool(evaluate)), self.rng_seed,
+                                            vp(self._draw.data_ptr()), vp(actions.data_ptr()), vp(last_action.data_ptr()),
+                                            p_u, p_oh, T, t, stream)
+            if rc != 0:
+                raise RuntimeError('rollout_select_actions failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
             # frozen chips are not stepped: the kernel reports reward 0 / constraints 0 / success 0 / terminated 1
             obs, _, _, info = self.env.step(actions, active=alive, record=True)
-            term = info['terminated'].bool()
             if record:
-                ep['u'][:, t, :, 0] = actions
-                ep['r'][:, t, 0] = info['team_reward']
-                ep['o_next'][:, t] = obs
-                ep['u_onehot'][:, t] = onehot
-                ep['padded'][:, t, 0] = ~alive
-                ep['terminated'][:, t, 0] = term
-            reward += info['team_reward']
-            constraints += info['constraints']
-            success += info['success']
-            steps += alive
-            if not evaluate and self.agents.args.epsilon_anneal_scale == 'step':
-                eps = torch.clamp(eps - self.anneal_epsilon * alive.sum(), min=self.min_epsilon)
-            last_action = onehot
-            alive = alive & ~term
-            if not self._capturing and (t + 1) % self.sync_every == 0 and not bool(alive.any()):
+                ep['o_next'][:, t] = obs  # rows of frozen chips are zeroed in one pass after the loop
+            cons = info['constraints']
+            rc = lib.rollout_post_step(E, T, t, vp(alive.data_ptr()), vp(info['terminated'].data_ptr()),
+                                       vp(info['team_reward'].data_ptr()), vp(cons.data_ptr()), int(cons.dtype == torch.float64),
+                                       vp(info['success'].data_ptr()), p_r, p_pad, p_term, vp(reward.data_ptr()),
+                                       vp(constraints.data_ptr()), vp(success.data_ptr()), vp(steps.data_ptr()),
+                                       vp(eps.data_ptr()), anneal, min_eps, vp(self._n_alive.data_ptr()),
+                                       vp(self._draw.data_ptr()), stream)
+            if rc != 0:
+                raise RuntimeError('rollout_post_step failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
+            t_played = t + 1
+            if not self._capturing and (t + 1) % self.sync_every == 0 and int(self._n_alive.item()) == 0:
                 break
         if record:  # padding rules of rollout.py:131-141 applied once: zeros, avail 0 where padded
+            if t_played > 1:  # o[t] of a chip that is still alive IS o_next[t-1]
+                ep['o'][:, 1:t_played] = ep['o_next'][:, :t_played - 1]
             valid = ~ep['padded']                                   # (E, T, 1)
             v4 = valid.unsqueeze(-1)
             for key in ('o', 'o_next', 'u', 'u_onehot'):
@@ -131,7 +160,7 @@ class Evaluator:
             ep['avail_u'][:] = v4
             ep['avail_u_next'][:] = v4
         steps = torch.where(success > 0, steps, torch.full_like(steps, self.episode_limit))
-        return reward, steps, constraints, success, ep, eps
+        return reward, steps, constraints, success, ep, eps.reshape(())
 
     def _generate_episode(self):
         """Greedy episode on every chip (rollout.py:41-67): per-chip reward, steps, constraints, success."""

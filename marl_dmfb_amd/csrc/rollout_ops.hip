@@ -1,0 +1,145 @@
+// rollout_ops.hip -- epsilon-greedy selection and per-step episode book-keeping of the lock-step rollout as two
+// launches (include/rollout_ops.h).  Tiny, latency-bound kernels: the point is the launch count, not bandwidth.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/rollout_ops.h"
+
+namespace {
+
+__device__ __forceinline__ void philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__global__ void k_select(const float *__restrict__ q, int rows, int n, int A, const float *__restrict__ eps_p, int evaluate,
+                         uint32_t k0, uint32_t k1, const uint32_t *__restrict__ draw_p, int32_t *__restrict__ actions, int8_t *__restrict__ last_onehot,
+                         int8_t *__restrict__ ep_u, int8_t *__restrict__ ep_onehot, int T, int t) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float *qr = q + (size_t)r * A;
+    int best = 0;
+    float bv = qr[0];
+    for (int k = 1; k < A; ++k) {
+        const float v = qr[k];
+        if (v > bv) { bv = v; best = k; }
+    }
+    int act = best;
+    if (!evaluate) {
+        uint32_t w[4];
+        philox(k0, k1, (uint32_t)r, *draw_p, 0u, 0x600u, w);
+        const float u1 = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
+        if (u1 < *eps_p) act = (int)__umulhi(w[1], (uint32_t)A);
+    }
+    actions[r] = act;
+    int8_t *lo = last_onehot + (size_t)r * A;
+    for (int k = 0; k < A; ++k) lo[k] = (int8_t)(k == act);
+    if (ep_u) {
+        const int e = r / n, a = r - e * n;
+        const size_t slot = ((size_t)e * T + t) * n + a;
+        ep_u[slot] = (int8_t)act;
+        if (ep_onehot) {
+            int8_t *eo = ep_onehot + slot * A;
+            for (int k = 0; k < A; ++k) eo[k] = (int8_t)(k == act);
+        }
+    }
+}
+
+constexpr int kPostBlock = 1024;
+
+__global__ __launch_bounds__(kPostBlock) void k_post(int E, int T, int t, uint8_t *__restrict__ alive, const uint8_t *__restrict__ term,
+                                                     const double *__restrict__ team_reward, const void *__restrict__ constraints, int cons_f64,
+                                                     const uint8_t *__restrict__ success, float *__restrict__ ep_r, uint8_t *__restrict__ ep_padded,
+                                                     uint8_t *__restrict__ ep_term, double *__restrict__ sum_reward, double *__restrict__ sum_cons,
+                                                     int64_t *__restrict__ sum_success, int64_t *__restrict__ steps, float *__restrict__ eps_p,
+                                                     float anneal, float min_eps, int32_t *__restrict__ n_alive_out, uint32_t *__restrict__ draw_p) {
+    __shared__ int s_cnt[2][kPostBlock / 64];
+    int was = 0, now = 0;
+    for (int e = threadIdx.x; e < E; e += kPostBlock) {
+        const int a = alive[e] != 0, tm = term[e] != 0;
+        const double tr = team_reward[e];
+        if (ep_r) ep_r[(size_t)e * T + t] = (float)tr;
+        if (ep_padded) ep_padded[(size_t)e * T + t] = (uint8_t)!a;
+        if (ep_term) ep_term[(size_t)e * T + t] = (uint8_t)tm;
+        sum_reward[e] += tr;
+        sum_cons[e] += cons_f64 ? ((const double *)constraints)[e] : (double)((const int32_t *)constraints)[e];
+        sum_success[e] += success[e];
+        steps[e] += a;
+        const int na = a && !tm;
+        alive[e] = (uint8_t)na;
+        was += a;
+        now += na;
+    }
+    for (int o = 32; o > 0; o >>= 1) { was += __shfl_down(was, o); now += __shfl_down(now, o); }
+    if ((threadIdx.x & 63) == 0) { s_cnt[0][threadIdx.x >> 6] = was; s_cnt[1][threadIdx.x >> 6] = now; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int w = 0, nw = 0;
+        for (int i = 0; i < kPostBlock / 64; ++i) { w += s_cnt[0][i]; nw += s_cnt[1][i]; }
+        if (anneal > 0.0f) *eps_p = fmaxf(*eps_p - anneal * (float)w, min_eps);
+        if (n_alive_out) *n_alive_out = nw;
+        if (draw_p) *draw_p += 1u;
+    }
+}
+
+thread_local int g_last = 0;
+
+int finish() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_last = (int)e;
+        if (getenv("DMFB_VEC_DEBUG")) fprintf(stderr, "rollout_ops: launch failed: %s\n", hipGetErrorString(e));
+        return ROLLOUT_ERR_HIP;
+    }
+    return ROLLOUT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rollout_select_actions(const float *d_q, int32_t n_envs, int32_t n_agents, int32_t n_actions, const float *d_epsilon,
+                           int32_t evaluate, uint64_t seed, const uint32_t *d_draw, int32_t *d_actions, int8_t *d_last_onehot,
+                           int8_t *d_ep_u, int8_t *d_ep_onehot, int32_t episode_limit, int32_t t, void *stream) {
+    if (!d_q || !d_actions || !d_last_onehot || n_envs < 0 || n_agents < 1 || n_actions < 1 || n_actions > 127 ||
+        (!evaluate && (!d_epsilon || !d_draw)) || (d_ep_u && (t < 0 || t >= episode_limit)))
+        return ROLLOUT_ERR_BAD_ARG;
+    const long rows = (long)n_envs * n_agents;
+    if (rows == 0) return ROLLOUT_OK;
+    if (rows > 0x7fffffffL) return ROLLOUT_ERR_BAD_ARG;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_select, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_q, (int)rows, n_agents, n_actions,
+                       d_epsilon, evaluate, (uint32_t)seed, (uint32_t)(seed >> 32), d_draw, d_actions, d_last_onehot, d_ep_u, d_ep_onehot,
+                       episode_limit, t);
+    return finish();
+}
+
+int rollout_post_step(int32_t n_envs, int32_t episode_limit, int32_t t, uint8_t *d_alive, const uint8_t *d_term,
+                      const double *d_team_reward, const void *d_constraints, int32_t constraints_f64,
+                      const uint8_t *d_success, float *d_ep_r, uint8_t *d_ep_padded, uint8_t *d_ep_terminated,
+                      double *d_sum_reward, double *d_sum_constraints, int64_t *d_sum_success, int64_t *d_steps,
+                      float *d_epsilon, float anneal, float min_epsilon, int32_t *d_n_alive, uint32_t *d_draw, void *stream) {
+    if (!d_alive || !d_term || !d_team_reward || !d_constraints || !d_success || !d_sum_reward || !d_sum_constraints ||
+        !d_sum_success || !d_steps || n_envs < 0 || (anneal > 0.0f && !d_epsilon) ||
+        ((d_ep_r || d_ep_padded || d_ep_terminated) && (t < 0 || t >= episode_limit)))
+        return ROLLOUT_ERR_BAD_ARG;
+    if (n_envs == 0) return ROLLOUT_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_post, dim3(1), dim3(kPostBlock), 0, (hipStream_t)stream, n_envs, episode_limit, t, d_alive, d_term, d_team_reward,
+                       d_constraints, constraints_f64, d_success, d_ep_r, d_ep_padded, d_ep_terminated, d_sum_reward, d_sum_constraints,
+                       d_sum_success, d_steps, d_epsilon, anneal, min_epsilon, d_n_alive, d_draw);
+    return finish();
+}
+
+int rollout_last_hip_error(void) { return g_last; }
+
+}  // extern "C"

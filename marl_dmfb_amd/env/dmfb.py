@@ -59,6 +59,7 @@ class VecDMFB:
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('VecDMFB runs on the GPU only (no CPU fallback)')
+        self.seed, self.env_id0 = int(seed), int(env_id0)
         self.width, self.length, self.n_agents, self.fov = width, length, n_agents, fov
         self.n_envs, self.stall, self.b_degrade = n_envs, bool(stall), bool(b_degrade)
         self.n_blocks = n_blocks

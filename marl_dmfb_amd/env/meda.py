@@ -52,6 +52,7 @@ class VecMEDA:
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('VecMEDA runs on the GPU only (no CPU fallback)')
+        self.seed, self.env_id0 = int(seed), int(env_id0)
         self.width, self.length, self.n_agents, self.fov, self.n_envs = width, length, n_agents, fov, n_envs
         self.cfg = _lib.MedaVecConfig(width, length, n_agents, fov, int(bool(b_degrade)), int(bool(with_maps)),
                                       float(per_degrade), n_envs, env_id0, seed, self.device.index or 0, int(version))

@@ -93,3 +93,14 @@ def test_crnn_ops_library_exports():
     # argument guards run on the host before anything touches the GPU
     assert lib.crnn_conv9_forward(None, 245, 4, None, None, None, None, 24, None, 600, None) == -1
     assert lib.gru_seq_forward(None, None, None, None, None, 4, 8, 128, None, None, None) == -1
+
+
+def test_rollout_ops_library_exports():
+    lib = _lib.rollout_ops()
+    txt = open(os.path.join(ROOT, 'include', 'rollout_ops.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    names = sorted(set(re.findall(r'\b(rollout_[a-z_0-9]+)\s*\(', txt)))
+    assert names == ['rollout_last_hip_error', 'rollout_post_step', 'rollout_select_actions']
+    for n in names:
+        assert hasattr(lib, n)
+    assert lib.rollout_select_actions(None, 4, 2, 5, None, 1, 0, None, None, None, None, None, 10, 0, None) == -1

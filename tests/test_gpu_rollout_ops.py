@@ -1,0 +1,102 @@
+"""rollout_select_actions / rollout_post_step (include/rollout_ops.h) against the op-by-op tensor formulation of
+the reference's per-step book-keeping (common/rollout.py:101-150, agent/agent.py:41-45)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _philox(k0, k1, c):
+    M0, M1 = 0xD2511F53, 0xCD9E8D57
+    c = [int(x) for x in c]
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c
+
+
+@pytest.mark.parametrize('evaluate', [True, False])
+def test_select_actions(evaluate):
+    from marl_dmfb_amd import _lib
+    lib = _lib.rollout_ops()
+    E, n, A, T, t = 37, 3, 5, 6, 4
+    g = torch.Generator(device='cuda').manual_seed(5)
+    q = torch.randn(E * n, A, device='cuda', generator=g)
+    q[3] = q[3, 0]  # ties -> first maximum
+    eps = torch.tensor([0.4], device='cuda')
+    draw = torch.tensor([7], dtype=torch.int32, device='cuda')
+    actions = torch.full((E, n), -1, dtype=torch.int32, device='cuda')
+    last = torch.full((E, n, A), 9, dtype=torch.int8, device='cuda')
+    ep_u = torch.zeros((E, T, n, 1), dtype=torch.int8, device='cuda')
+    ep_oh = torch.zeros((E, T, n, A), dtype=torch.int8, device='cuda')
+    seed = 0x1234567811223344
+    vp = C.c_void_p
+    rc = lib.rollout_select_actions(vp(q.data_ptr()), E, n, A, vp(eps.data_ptr()), int(evaluate), seed, vp(draw.data_ptr()),
+                                    vp(actions.data_ptr()), vp(last.data_ptr()), vp(ep_u.data_ptr()), vp(ep_oh.data_ptr()), T, t, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    qn = q.cpu().numpy()
+    want = np.zeros(E * n, np.int64)
+    n_rand = 0
+    for r in range(E * n):
+        a = int(np.argmax(qn[r]))
+        if not evaluate:
+            w = _philox(seed & 0xFFFFFFFF, seed >> 32, (r, 7, 0, 0x600))
+            if np.float32(w[0] >> 8) * np.float32(2.0 ** -24) < np.float32(0.4):
+                a = (w[1] * A) >> 32
+                n_rand += 1
+        want[r] = a
+    if not evaluate:
+        assert 0.25 * E * n < n_rand < 0.55 * E * n
+    assert np.array_equal(actions.cpu().numpy().reshape(-1), want)
+    oh = np.eye(A, dtype=np.int8)[want].reshape(E, n, A)
+    assert np.array_equal(last.cpu().numpy(), oh)
+    assert np.array_equal(ep_u[:, t, :, 0].cpu().numpy(), want.reshape(E, n))
+    assert np.array_equal(ep_oh[:, t].cpu().numpy(), oh)
+    assert int(ep_u.abs().sum()) == int(np.abs(want).sum()) and int(ep_oh.sum()) == E * n   # other slots untouched
+
+
+@pytest.mark.parametrize('f64', [False, True])
+def test_post_step(f64):
+    from marl_dmfb_amd import _lib
+    lib = _lib.rollout_ops()
+    E, T, t = 2500, 7, 3
+    g = torch.Generator(device='cuda').manual_seed(1)
+    alive = (torch.rand(E, device='cuda', generator=g) < 0.7).to(torch.uint8)
+    term = (torch.rand(E, device='cuda', generator=g) < 0.3).to(torch.uint8)
+    tr = torch.randn(E, device='cuda', generator=g, dtype=torch.float64)
+    cons = torch.randint(0, 4, (E,), device='cuda', generator=g, dtype=torch.int32)
+    cons_in = cons.double() * 0.6 if f64 else cons
+    succ = (torch.rand(E, device='cuda', generator=g) < 0.2).to(torch.uint8)
+    ep_r = torch.zeros((E, T, 1), device='cuda')
+    ep_pad = torch.ones((E, T, 1), dtype=torch.bool, device='cuda')
+    ep_term = torch.ones((E, T, 1), dtype=torch.bool, device='cuda')
+    s_r = torch.randn(E, device='cuda', generator=g, dtype=torch.float64)
+    s_c = torch.zeros(E, dtype=torch.float64, device='cuda')
+    s_s = torch.zeros(E, dtype=torch.int64, device='cuda')
+    steps = torch.arange(E, device='cuda')
+    eps = torch.tensor([0.9], device='cuda')
+    n_alive = torch.zeros(1, dtype=torch.int32, device='cuda')
+    draw = torch.tensor([41], dtype=torch.int32, device='cuda')
+    a0, r0, st0 = alive.clone(), s_r.clone(), steps.clone()
+    vp = C.c_void_p
+    rc = lib.rollout_post_step(E, T, t, vp(alive.data_ptr()), vp(term.data_ptr()), vp(tr.data_ptr()), vp(cons_in.data_ptr()), int(f64),
+                               vp(succ.data_ptr()), vp(ep_r.data_ptr()), vp(ep_pad.data_ptr()), vp(ep_term.data_ptr()),
+                               vp(s_r.data_ptr()), vp(s_c.data_ptr()), vp(s_s.data_ptr()), vp(steps.data_ptr()), vp(eps.data_ptr()),
+                               1e-4, 0.05, vp(n_alive.data_ptr()), vp(draw.data_ptr()), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(ep_r[:, t, 0], tr.float())
+    assert float(ep_r[:, :t].abs().sum()) == 0.0 and float(ep_r[:, t + 1:].abs().sum()) == 0.0
+    assert torch.equal(ep_pad[:, t, 0], a0 == 0) and torch.equal(ep_term[:, t, 0], term != 0)
+    assert bool(ep_pad[:, :t].all()) and bool(ep_term[:, t + 1:].all())
+    assert torch.equal(s_r, r0 + tr) and torch.equal(s_c, cons_in.double()) and torch.equal(s_s, succ.long())
+    assert torch.equal(steps, st0 + a0.long())
+    assert torch.equal(alive, a0 & (1 - term))
+    assert int(n_alive) == int(alive.sum()) and int(draw) == 42
+    want_eps = max(np.float32(0.9) - np.float32(1e-4) * np.float32(int(a0.sum())), np.float32(0.05))
+    assert abs(float(eps) - float(want_eps)) < 1e-6
