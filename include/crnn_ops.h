@@ -48,6 +48,10 @@ int crnn_front9_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d
 int crnn_conv9_forward_train(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_w1, const float *d_b1,
                              const float *d_w2, const float *d_b2, int od, float *d_out, int64_t out_stride, float *d_a1_save,
                              void *stream);
+/* crnn_front9_forward + the saved conv1 activations: the whole GRU input row for the eval network in one launch. */
+int crnn_front9_forward_train(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
+                              const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
+                              const float *d_mlp_b, int od, float *d_out, int64_t out_stride, float *d_a1_save, void *stream);
 int crnn_conv9_backward_parts(int od);
 int crnn_conv9_a1_floats(int od);
 int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_a1_save, const float *d_out,

@@ -143,6 +143,7 @@ def crnn_ops():
     vp, i64 = C.c_void_p, C.c_int64
     lib.crnn_conv9_forward.argtypes = [vp, i64, i64, vp, vp, vp, vp, C.c_int, vp, i64, vp]
     lib.crnn_front9_forward.argtypes = [vp, i64, vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, i64, vp]
+    lib.crnn_front9_forward_train.argtypes = [vp, i64, vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, i64, vp, vp]
     lib.crnn_conv9_forward_train.argtypes = [vp, i64, i64, vp, vp, vp, vp, C.c_int, vp, i64, vp, vp]
     lib.crnn_conv9_backward_parts.argtypes = [C.c_int]
     lib.crnn_conv9_a1_floats.argtypes = [C.c_int]

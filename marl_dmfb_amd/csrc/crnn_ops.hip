@@ -468,6 +468,18 @@ int crnn_conv9_forward_train(const int8_t *d_obs, int64_t obs_stride, int64_t ro
     return CRNN_ERR_UNSUPPORTED;
 }
 
+int crnn_front9_forward_train(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
+                              const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
+                              const float *d_mlp_b, int od, float *d_out, int64_t out_stride, float *d_a1_save, void *stream) {
+    if (!d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_mlp_w || !d_mlp_b || !d_out || !d_a1_save || rows < 0 || obs_stride < 245 ||
+        out_stride < od * 25 + 10 || n_actions < 0 || n_actions > 16)
+        return CRNN_ERR_BAD_ARG;
+    if (rows == 0) return CRNN_OK;
+    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, d_a1_save, (hipStream_t)stream);
+    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, d_a1_save, (hipStream_t)stream);
+    return CRNN_ERR_UNSUPPORTED;
+}
+
 int crnn_conv9_backward_parts(int od) { return od == 24 ? GeoB<24>::PART : od == 32 ? GeoB<32>::PART : CRNN_ERR_UNSUPPORTED; }
 int crnn_conv9_a1_floats(int od) { return od * kA1Stride; }
 

@@ -98,6 +98,91 @@ class _ConvFront9(torch.autograd.Function):
         return None, g_w1, g_b1, g_w2, g_b2
 
 
+class _Front9Train(torch.autograd.Function):
+    """The whole GRU input row x = cat([conv features, relu(mlp1([dir, last action]))]) of the eval network in ONE
+    launch (crnn_front9_forward_train) with a hand-written backward: crnn_conv9_backward for the four conv tensors
+    (reading the row-strided gradient in place) and two small split-K GEMMs for mlp1."""
+
+    @staticmethod
+    def forward(ctx, obs_i8, onehot_i8, w1, b1, w2, b2, mlp_w, mlp_b):
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.crnn_ops()
+        vp = C.c_void_p
+        obs_i8, onehot_i8 = obs_i8.contiguous(), onehot_i8.contiguous()
+        R, od, A = obs_i8.shape[0], w1.shape[0], onehot_i8.shape[1]
+        x = torch.empty((R, od * 25 + 10), dtype=torch.float32, device=obs_i8.device)
+        a1 = torch.empty((R, lib.crnn_conv9_a1_floats(od)), dtype=torch.float32, device=obs_i8.device)
+        w1c, b1c, w2c, b2c, mwc, mbc = (t.detach().contiguous() for t in (w1, b1, w2, b2, mlp_w, mlp_b))
+        rc = lib.crnn_front9_forward_train(vp(obs_i8.data_ptr()), obs_i8.stride(0), vp(onehot_i8.data_ptr()), A, R, vp(w1c.data_ptr()),
+                                           vp(b1c.data_ptr()), vp(w2c.data_ptr()), vp(b2c.data_ptr()), vp(mwc.data_ptr()),
+                                           vp(mbc.data_ptr()), od, vp(x.data_ptr()), x.stride(0), vp(a1.data_ptr()),
+                                           vp(torch.cuda.current_stream(obs_i8.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('crnn_front9_forward_train failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
+        ctx.save_for_backward(obs_i8, onehot_i8, a1, x, w2c)
+        ctx.shapes = (w1.shape, w2.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.crnn_ops()
+        vp = C.c_void_p
+        obs_i8, onehot_i8, a1, x, w2c = ctx.saved_tensors
+        (s1, s2) = ctx.shapes
+        od, R = s1[0], obs_i8.shape[0]
+        if g.stride(1) != 1:
+            g = g.contiguous()
+        plen = lib.crnn_conv9_backward_parts(od)
+        part = torch.empty((_ConvFront9.N_PART, plen), dtype=torch.float32, device=g.device)
+        n2 = od * od * 9
+        tot = torch.empty(n2 + od + od * 27 + od, dtype=torch.float32, device=g.device)
+        rc = lib.crnn_conv9_backward(vp(obs_i8.data_ptr()), obs_i8.stride(0), R, vp(a1.data_ptr()), vp(x.data_ptr()), x.stride(0),
+                                     vp(g.data_ptr()), g.stride(0), vp(w2c.data_ptr()), od, vp(part.data_ptr()), _ConvFront9.N_PART,
+                                     vp(tot.data_ptr()), vp(torch.cuda.current_stream(g.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('crnn_conv9_backward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
+        gz = g[:, od * 25:] * (x[:, od * 25:] > 0)
+        vec = torch.cat([obs_i8[:, 243:245].float(), onehot_i8.float()], dim=1)
+        g_mw = _wgrad_splitk(gz.contiguous(), vec)
+        return (None, None, tot[n2 + od:n2 + od + od * 27].view(s1), tot[n2 + od + od * 27:], tot[:n2].view(s2), tot[n2:n2 + od],
+                g_mw, gz.sum(0))
+
+
+class _LinearSplitK(torch.autograd.Function):
+    """x @ W^T (+ b) for very tall x: the weight gradient g^T @ x has few outputs and a reduction over all the rows,
+    which is done as a split-K batched GEMM (`_wgrad_splitk`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, weight.t()) if bias is not None else torch.matmul(x, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.matmul(g, w) if ctx.needs_input_grad[0] else None
+        return gx, _wgrad_splitk(g, x), (g.sum(0) if ctx.has_bias else None)
+
+
+def _wgrad_splitk(g2d, x2d):
+    """g2d^T @ x2d for tall operands (M rows, few output elements): the reduction over M is split into S
+    independent chunks (batched GEMM) so that the whole chip works on it, then the S partials are added."""
+    M = g2d.shape[0]
+    S = 1
+    for cand in (64, 32, 16, 8, 4, 2):
+        if M % cand == 0 and M // cand >= 512:
+            S = cand
+            break
+    if S == 1:
+        return torch.matmul(g2d.t(), x2d)
+    return torch.bmm(g2d.view(S, M // S, -1).transpose(1, 2), x2d.view(S, M // S, -1)).sum(0)
+
+
 class _GRUSeq(torch.autograd.Function):
     """GRU cell unrolled over a whole sequence as ONE autograd node (GPU only).
 
@@ -188,8 +273,10 @@ class _GRUSeqHip(torch.autograd.Function):
                                   vp(torch.cuda.current_stream(hs.device).cuda_stream))
         if rc != 0:
             raise RuntimeError('gru_seq_backward failed: %d (hip %d)' % (rc, lib.gru_last_hip_error()))
-        h_prev = torch.cat([h0c.unsqueeze(0), hs[:-1]], dim=0)
-        d_w_hh = torch.matmul(d_hg.view(T * R, 3 * H).t(), h_prev.view(T * R, H))
+        # dW_hh = sum_t d_hg[t]^T h_{t-1}: h_0 separately, the rest straight from the saved hs (no concatenated copy)
+        d_w_hh = torch.matmul(d_hg[0].t(), h0c)
+        if T > 1:
+            d_w_hh = d_w_hh + _wgrad_splitk(d_hg[1:].reshape((T - 1) * R, 3 * H), hs[:-1].reshape((T - 1) * R, H))
         return d_ig, d_h0, d_w_hh, d_ig.sum(dim=(0, 1)), d_hg.sum(dim=(0, 1))
 
 
@@ -280,10 +367,10 @@ class CRNN(nn.Module):
         h = h0.reshape(-1, self.rnn_hidden_dim)
         hs = []
         if x_seq.is_cuda:
-            igates = torch.matmul(x_seq.reshape(T * R, -1), self.rnn.weight_ih.t()).view(T, R, -1)
+            igates = _LinearSplitK.apply(x_seq.reshape(T * R, -1), self.rnn.weight_ih, None).view(T, R, -1)
             hseq = gru_sequence(igates, h, self.rnn.weight_hh, self.rnn.bias_ih, self.rnn.bias_hh,
                                 getattr(self, 'gru_impl', 'hip'))
-            q = self.fc1(hseq.view(T * R, -1)).view(T, R, -1)
+            q = _LinearSplitK.apply(hseq.view(T * R, -1), self.fc1.weight, self.fc1.bias).view(T, R, -1)
             return q, hseq[-1]
         else:
             for t in range(T):
@@ -343,6 +430,9 @@ class CRNN(nn.Module):
         """GRU input rows for the eval network inside learn (gradients flow to every parameter):
         HIP conv front end with its own backward + the small vector MLP in torch."""
         c1, c2 = self.convs[0], self.convs[1]
+        if self.mlp1.in_features == 2 + self.n_actions and self.n_actions <= 16 and self.mlp1.out_features == 10:
+            return _Front9Train.apply(obs_i8, la_rows.to(torch.int8), c1.weight, c1.bias, c2.weight, c2.bias,
+                                      self.mlp1.weight, self.mlp1.bias)
         pix = _ConvFront9.apply(obs_i8, c1.weight, c1.bias, c2.weight, c2.bias)
         vec = torch.cat([obs_i8[:, self.n_pixel:].float(), la_rows.float()], dim=1)
         return torch.cat([pix, f.relu(self.mlp1(vec))], dim=1)

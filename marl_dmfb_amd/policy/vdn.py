@@ -188,7 +188,9 @@ class VDN:
         obs_seq = obs_seq.permute(1, 0, 2, 3).reshape(T + 1, B * self.n_agents, -1)
         la = None
         if self.args.last_action:
-            uo = _t(batch['u_onehot'], dev, torch.float32)
+            src = batch['u_onehot']
+            keep = isinstance(src, torch.Tensor) and src.dtype == torch.int8 and o.dtype == torch.int8
+            uo = _t(src, dev, torch.int8 if keep else torch.float32)   # int8 stays int8 for the HIP front end
             la = torch.cat([torch.zeros_like(uo[:, :1]), uo[:, :T]], dim=1)
             la = la.permute(1, 0, 2, 3).reshape(T + 1, B * self.n_agents, -1)
         return obs_seq, la
@@ -201,7 +203,7 @@ class VDN:
             return net.features_obs_train(obs_rows, la_rows)  # eval net: HIP conv forward + backward
         x = obs_rows.float()
         if la_rows is not None:
-            x = torch.cat([x, la_rows], dim=1)
+            x = torch.cat([x, la_rows.float()], dim=1)
         return net.features(x)
 
     def get_q_values(self, batch, max_episode_len):
