@@ -57,6 +57,13 @@ int crnn_conv9_a1_floats(int od);
 int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_a1_save, const float *d_out,
                         int64_t out_stride, const float *d_grad_out, int64_t grad_stride, const float *d_w2, int od,
                         float *d_part, int n_part, float *d_grads, void *stream);
+/* The same gradients WITHOUT saved activations: conv1 is recomputed per row block on the matrix cores, the three
+ * gradient contractions run as f32 MFMA GEMMs (csrc/crnn_mfma_bwd.h).  d_out / d_grad_out as above;
+ * d_part float32[n_part][crnn_conv9_backward_mfma_parts(od)] scratch (n_part <= 256). */
+int crnn_conv9_backward_mfma_parts(int od);
+int crnn_conv9_backward_mfma(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
+                             const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1,
+                             const float *d_w2, int od, float *d_part, int n_part, float *d_grads, void *stream);
 int crnn_last_hip_error(void);
 
 /* ---- GRU cell unrolled over an episode (network/base_net.py:56,69 nn.GRUCell; policy/vdn.py:174-191 time loop) ----

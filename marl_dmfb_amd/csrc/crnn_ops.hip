@@ -19,6 +19,7 @@
 
 #include "../../include/crnn_ops.h"
 #include "crnn_mfma.h"
+#include "crnn_mfma_bwd.h"
 
 namespace {
 
@@ -431,6 +432,26 @@ int launch_bwd(const int8_t *obs, long obs_stride, long rows, const float *a1_sa
     return CRNN_OK;
 }
 
+template <int OD>
+int launch_bwd_mfma(const int8_t *obs, long obs_stride, long rows, const float *a2, long a2_stride, const float *g, long g_stride,
+                    const float *w1, const float *b1, const float *w2, float *part, int grid, float *grads, hipStream_t s) {
+    using G = crnn_mfma::GeoMB<OD>;
+    const size_t lds = G::LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)crnn_mfma::k_conv9_bwd_mfma<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
+        attr_set = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((crnn_mfma::k_conv9_bwd_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockB), lds, s, obs, obs_stride, rows, a2, a2_stride, g,
+                       g_stride, w1, b1, w2, part);
+    hipLaunchKernelGGL((crnn_mfma::k_conv9_bwd_mfma_reduce<OD>), dim3((G::PART + 255) / 256), dim3(256), 0, s, part, grid, grads);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
+    return CRNN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -490,6 +511,21 @@ int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, c
         return CRNN_ERR_BAD_ARG;
     if (od == 24) return launch_bwd<24>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, (hipStream_t)stream);
     if (od == 32) return launch_bwd<32>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, (hipStream_t)stream);
+    return CRNN_ERR_UNSUPPORTED;
+}
+
+int crnn_conv9_backward_mfma_parts(int od) {
+    return od == 24 ? crnn_mfma::GeoMB<24>::PART : od == 32 ? crnn_mfma::GeoMB<32>::PART : CRNN_ERR_UNSUPPORTED;
+}
+
+int crnn_conv9_backward_mfma(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
+                             const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1,
+                             const float *d_w2, int od, float *d_part, int n_part, float *d_grads, void *stream) {
+    if (!d_obs || !d_out || !d_grad_out || !d_w1 || !d_b1 || !d_w2 || !d_part || !d_grads || rows <= 0 || n_part < 1 || n_part > 256 ||
+        obs_stride < 243 || out_stride < od * 25 || grad_stride < od * 25)
+        return CRNN_ERR_BAD_ARG;
+    if (od == 24) return launch_bwd_mfma<24>(d_obs, obs_stride, rows, d_out, out_stride, d_grad_out, grad_stride, d_w1, d_b1, d_w2, d_part, n_part, d_grads, (hipStream_t)stream);
+    if (od == 32) return launch_bwd_mfma<32>(d_obs, obs_stride, rows, d_out, out_stride, d_grad_out, grad_stride, d_w1, d_b1, d_w2, d_part, n_part, d_grads, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
 }
 

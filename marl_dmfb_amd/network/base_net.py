@@ -98,10 +98,18 @@ class _ConvFront9(torch.autograd.Function):
         return None, g_w1, g_b1, g_w2, g_b2
 
 
+def _conv_bwd_mfma():
+    """CRNN_CONV_BWD=mfma selects the matrix-core backward that recomputes conv1 (csrc/crnn_mfma_bwd.h; correct, but its
+    col2im phase scatters through LDS float atomics and is 2x slower than the VALU kernel: 3.2 vs 1.65 ms per 81920
+    rows on MI355X).  Default: the VALU backward kernel, which reads the conv1 activations saved by the forward."""
+    import os
+    return os.environ.get('CRNN_CONV_BWD', 'valu') == 'mfma'
+
+
 class _Front9Train(torch.autograd.Function):
     """The whole GRU input row x = cat([conv features, relu(mlp1([dir, last action]))]) of the eval network in ONE
-    launch (crnn_front9_forward_train) with a hand-written backward: crnn_conv9_backward for the four conv tensors
-    (reading the row-strided gradient in place) and two small split-K GEMMs for mlp1."""
+    launch (crnn_front9_forward[_train]) with a hand-written backward: crnn_conv9_backward[_mfma] for the four conv
+    tensors (reading the row-strided gradient in place) and two small split-K GEMMs for mlp1."""
 
     @staticmethod
     def forward(ctx, obs_i8, onehot_i8, w1, b1, w2, b2, mlp_w, mlp_b):
@@ -112,15 +120,23 @@ class _Front9Train(torch.autograd.Function):
         obs_i8, onehot_i8 = obs_i8.contiguous(), onehot_i8.contiguous()
         R, od, A = obs_i8.shape[0], w1.shape[0], onehot_i8.shape[1]
         x = torch.empty((R, od * 25 + 10), dtype=torch.float32, device=obs_i8.device)
-        a1 = torch.empty((R, lib.crnn_conv9_a1_floats(od)), dtype=torch.float32, device=obs_i8.device)
         w1c, b1c, w2c, b2c, mwc, mbc = (t.detach().contiguous() for t in (w1, b1, w2, b2, mlp_w, mlp_b))
-        rc = lib.crnn_front9_forward_train(vp(obs_i8.data_ptr()), obs_i8.stride(0), vp(onehot_i8.data_ptr()), A, R, vp(w1c.data_ptr()),
-                                           vp(b1c.data_ptr()), vp(w2c.data_ptr()), vp(b2c.data_ptr()), vp(mwc.data_ptr()),
-                                           vp(mbc.data_ptr()), od, vp(x.data_ptr()), x.stride(0), vp(a1.data_ptr()),
-                                           vp(torch.cuda.current_stream(obs_i8.device).cuda_stream))
+        stream = vp(torch.cuda.current_stream(obs_i8.device).cuda_stream)
+        ctx.mfma = _conv_bwd_mfma()
+        if ctx.mfma:
+            a1 = w1c  # placeholder: nothing is saved, the backward recomputes conv1
+            rc = lib.crnn_front9_forward(vp(obs_i8.data_ptr()), obs_i8.stride(0), vp(onehot_i8.data_ptr()), A, R, vp(w1c.data_ptr()),
+                                         vp(b1c.data_ptr()), vp(w2c.data_ptr()), vp(b2c.data_ptr()), vp(mwc.data_ptr()),
+                                         vp(mbc.data_ptr()), od, vp(x.data_ptr()), x.stride(0), stream)
+        else:
+            a1 = torch.empty((R, lib.crnn_conv9_a1_floats(od)), dtype=torch.float32, device=obs_i8.device)
+            rc = lib.crnn_front9_forward_train(vp(obs_i8.data_ptr()), obs_i8.stride(0), vp(onehot_i8.data_ptr()), A, R,
+                                               vp(w1c.data_ptr()), vp(b1c.data_ptr()), vp(w2c.data_ptr()), vp(b2c.data_ptr()),
+                                               vp(mwc.data_ptr()), vp(mbc.data_ptr()), od, vp(x.data_ptr()), x.stride(0),
+                                               vp(a1.data_ptr()), stream)
         if rc != 0:
-            raise RuntimeError('crnn_front9_forward_train failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
-        ctx.save_for_backward(obs_i8, onehot_i8, a1, x, w2c)
+            raise RuntimeError('crnn_front9_forward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
+        ctx.save_for_backward(obs_i8, onehot_i8, a1, x, w1c, b1c, w2c)
         ctx.shapes = (w1.shape, w2.shape)
         return x
 
@@ -130,18 +146,25 @@ class _Front9Train(torch.autograd.Function):
         from .. import _lib
         lib = _lib.crnn_ops()
         vp = C.c_void_p
-        obs_i8, onehot_i8, a1, x, w2c = ctx.saved_tensors
+        obs_i8, onehot_i8, a1, x, w1c, b1c, w2c = ctx.saved_tensors
         (s1, s2) = ctx.shapes
         od, R = s1[0], obs_i8.shape[0]
         if g.stride(1) != 1:
             g = g.contiguous()
-        plen = lib.crnn_conv9_backward_parts(od)
-        part = torch.empty((_ConvFront9.N_PART, plen), dtype=torch.float32, device=g.device)
         n2 = od * od * 9
         tot = torch.empty(n2 + od + od * 27 + od, dtype=torch.float32, device=g.device)
-        rc = lib.crnn_conv9_backward(vp(obs_i8.data_ptr()), obs_i8.stride(0), R, vp(a1.data_ptr()), vp(x.data_ptr()), x.stride(0),
-                                     vp(g.data_ptr()), g.stride(0), vp(w2c.data_ptr()), od, vp(part.data_ptr()), _ConvFront9.N_PART,
-                                     vp(tot.data_ptr()), vp(torch.cuda.current_stream(g.device).cuda_stream))
+        stream = vp(torch.cuda.current_stream(g.device).cuda_stream)
+        if ctx.mfma:
+            part = torch.empty((_ConvFront9.N_PART, lib.crnn_conv9_backward_mfma_parts(od)), dtype=torch.float32, device=g.device)
+            rc = lib.crnn_conv9_backward_mfma(vp(obs_i8.data_ptr()), obs_i8.stride(0), R, vp(x.data_ptr()), x.stride(0),
+                                              vp(g.data_ptr()), g.stride(0), vp(w1c.data_ptr()), vp(b1c.data_ptr()),
+                                              vp(w2c.data_ptr()), od, vp(part.data_ptr()), _ConvFront9.N_PART, vp(tot.data_ptr()),
+                                              stream)
+        else:
+            part = torch.empty((_ConvFront9.N_PART, lib.crnn_conv9_backward_parts(od)), dtype=torch.float32, device=g.device)
+            rc = lib.crnn_conv9_backward(vp(obs_i8.data_ptr()), obs_i8.stride(0), R, vp(a1.data_ptr()), vp(x.data_ptr()), x.stride(0),
+                                         vp(g.data_ptr()), g.stride(0), vp(w2c.data_ptr()), od, vp(part.data_ptr()),
+                                         _ConvFront9.N_PART, vp(tot.data_ptr()), stream)
         if rc != 0:
             raise RuntimeError('crnn_conv9_backward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
         gz = g[:, od * 25:] * (x[:, od * 25:] > 0)

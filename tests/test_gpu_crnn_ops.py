@@ -133,3 +133,36 @@ def test_recurrent_seq_hip_equals_aten_path():
     np.testing.assert_allclose(res['hip'][1].cpu().numpy(), res['aten'][1].cpu().numpy(), rtol=1e-4, atol=1e-5)
     for g1, g2 in zip(res['hip'][2], res['aten'][2]):
         assert torch.linalg.norm(g1 - g2) <= 1e-4 * torch.linalg.norm(g2)
+
+
+@pytest.mark.parametrize('bwd', ['valu', 'mfma'])
+@pytest.mark.parametrize('od,rows', [(24, 20000), (32, 5003), (24, 11), (24, 8)])
+def test_front9_train_node_matches_torch_autograd(od, rows, bwd, monkeypatch):
+    """_Front9Train (fused forward incl. mlp1; VALU backward on saved activations, or the MFMA backward that recomputes
+    conv1) against float64 torch autograd of the reference network's front end (network/base_net.py:59-68).  Same
+    tolerance rationale as the VALU pair above."""
+    from marl_dmfb_amd.network.base_net import CRNN, _Front9Train
+    monkeypatch.setenv('CRNN_CONV_BWD', bwd)
+    a = types.SimpleNamespace(obs_shape=(3, 9, 9, 2, 245), hyper_hidden_dim=od, rnn_hidden_dim=128, n_actions=5, fov=9)
+    torch.manual_seed(od * 11 + rows)
+    net = CRNN(a).cuda()
+    obs = torch.randint(-3, 8, (rows, 245), dtype=torch.int8, device='cuda')
+    oh = torch.nn.functional.one_hot(torch.randint(0, 5, (rows,), device='cuda'), 5).to(torch.int8)
+    gout = torch.randn(rows, od * 25 + 10, device='cuda')
+    c1, c2 = net.convs
+    x = _Front9Train.apply(obs, oh, c1.weight, c1.bias, c2.weight, c2.bias, net.mlp1.weight, net.mlp1.bias)
+    (x * gout).sum().backward()
+    params = (c1.weight, c1.bias, c2.weight, c2.bias, net.mlp1.weight, net.mlp1.bias)
+    got = [p.grad.detach().cpu().clone() for p in params]
+    ref = CRNN(a).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in net.state_dict().items()})
+    inp = torch.cat([obs.double().cpu(), oh.double().cpu()], dim=1)
+    xr = ref.features(inp)
+    np.testing.assert_allclose(x.detach().cpu().numpy(), xr.detach().numpy(), rtol=1e-4, atol=1e-4)
+    (xr * gout.double().cpu()).sum().backward()
+    r1, r2 = ref.convs
+    for g, r in zip(got, (r1.weight.grad, r1.bias.grad, r2.weight.grad, r2.bias.grad, ref.mlp1.weight.grad, ref.mlp1.bias.grad)):
+        r = r.float().numpy()
+        g = g.numpy()
+        assert np.linalg.norm(g - r) <= 2e-3 * np.linalg.norm(r)
+        assert np.abs(g - r).max() <= 1e-2 * np.abs(r).max()
