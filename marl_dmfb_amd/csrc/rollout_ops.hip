@@ -54,17 +54,21 @@ __global__ void k_select(const float *__restrict__ q, int rows, int n, int A, co
     }
 }
 
-constexpr int kPostBlock = 1024;
+constexpr int kPostBlock = 256;
 
+// One thread per chip; the two live-chip counts go through a 4-int device workspace (ws[0] = alive after, published by
+// the last workgroup; ws[1], ws[2] = running sums; ws[3] = ticket) so that any number of workgroups can take part.
 __global__ __launch_bounds__(kPostBlock) void k_post(int E, int T, int t, uint8_t *__restrict__ alive, const uint8_t *__restrict__ term,
                                                      const double *__restrict__ team_reward, const void *__restrict__ constraints, int cons_f64,
                                                      const uint8_t *__restrict__ success, float *__restrict__ ep_r, uint8_t *__restrict__ ep_padded,
                                                      uint8_t *__restrict__ ep_term, double *__restrict__ sum_reward, double *__restrict__ sum_cons,
                                                      int64_t *__restrict__ sum_success, int64_t *__restrict__ steps, float *__restrict__ eps_p,
-                                                     float anneal, float min_eps, int32_t *__restrict__ n_alive_out, uint32_t *__restrict__ draw_p) {
+                                                     float anneal, float min_eps, int32_t *__restrict__ ws, uint32_t *__restrict__ draw_p) {
     __shared__ int s_cnt[2][kPostBlock / 64];
+    __shared__ int s_last;
     int was = 0, now = 0;
-    for (int e = threadIdx.x; e < E; e += kPostBlock) {
+    const int e = blockIdx.x * kPostBlock + threadIdx.x;
+    if (e < E) {
         const int a = alive[e] != 0, tm = term[e] != 0;
         const double tr = team_reward[e];
         if (ep_r) ep_r[(size_t)e * T + t] = (float)tr;
@@ -76,8 +80,8 @@ __global__ __launch_bounds__(kPostBlock) void k_post(int E, int T, int t, uint8_
         steps[e] += a;
         const int na = a && !tm;
         alive[e] = (uint8_t)na;
-        was += a;
-        now += na;
+        was = a;
+        now = na;
     }
     for (int o = 32; o > 0; o >>= 1) { was += __shfl_down(was, o); now += __shfl_down(now, o); }
     if ((threadIdx.x & 63) == 0) { s_cnt[0][threadIdx.x >> 6] = was; s_cnt[1][threadIdx.x >> 6] = now; }
@@ -85,9 +89,18 @@ __global__ __launch_bounds__(kPostBlock) void k_post(int E, int T, int t, uint8_
     if (threadIdx.x == 0) {
         int w = 0, nw = 0;
         for (int i = 0; i < kPostBlock / 64; ++i) { w += s_cnt[0][i]; nw += s_cnt[1][i]; }
-        if (anneal > 0.0f) *eps_p = fmaxf(*eps_p - anneal * (float)w, min_eps);
-        if (n_alive_out) *n_alive_out = nw;
-        if (draw_p) *draw_p += 1u;
+        atomicAdd(&ws[1], w);
+        atomicAdd(&ws[2], nw);
+        __threadfence();
+        s_last = atomicAdd(&ws[3], 1) == (int)gridDim.x - 1;
+        if (s_last) {  // every workgroup has added its counts
+            __threadfence();
+            const int wt = atomicAdd(&ws[1], 0), nt = atomicAdd(&ws[2], 0);
+            if (anneal > 0.0f) *eps_p = fmaxf(*eps_p - anneal * (float)wt, min_eps);
+            ws[0] = nt;
+            ws[1] = 0; ws[2] = 0; ws[3] = 0;
+            if (draw_p) *draw_p += 1u;
+        }
     }
 }
 
@@ -129,12 +142,12 @@ int rollout_post_step(int32_t n_envs, int32_t episode_limit, int32_t t, uint8_t 
                       double *d_sum_reward, double *d_sum_constraints, int64_t *d_sum_success, int64_t *d_steps,
                       float *d_epsilon, float anneal, float min_epsilon, int32_t *d_n_alive, uint32_t *d_draw, void *stream) {
     if (!d_alive || !d_term || !d_team_reward || !d_constraints || !d_success || !d_sum_reward || !d_sum_constraints ||
-        !d_sum_success || !d_steps || n_envs < 0 || (anneal > 0.0f && !d_epsilon) ||
+        !d_sum_success || !d_steps || !d_n_alive || n_envs < 0 || (anneal > 0.0f && !d_epsilon) ||
         ((d_ep_r || d_ep_padded || d_ep_terminated) && (t < 0 || t >= episode_limit)))
         return ROLLOUT_ERR_BAD_ARG;
     if (n_envs == 0) return ROLLOUT_OK;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_post, dim3(1), dim3(kPostBlock), 0, (hipStream_t)stream, n_envs, episode_limit, t, d_alive, d_term, d_team_reward,
+    hipLaunchKernelGGL(k_post, dim3((unsigned)((n_envs + kPostBlock - 1) / kPostBlock)), dim3(kPostBlock), 0, (hipStream_t)stream, n_envs, episode_limit, t, d_alive, d_term, d_team_reward,
                        d_constraints, constraints_f64, d_success, d_ep_r, d_ep_padded, d_ep_terminated, d_sum_reward, d_sum_constraints,
                        d_sum_success, d_steps, d_epsilon, anneal, min_epsilon, d_n_alive, d_draw);
     return finish();
