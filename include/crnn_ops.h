@@ -77,9 +77,13 @@ int gru_seq_forward(const float *d_igates, const float *d_h0, const float *d_w_h
 /* Backward through time of the above: d_grad_hs float32[T][R][H] = dL/dh_t from the consumers of each step.
  * Writes d_d_igates float32[T][R][3H] (gradient w.r.t. d_igates = w.r.t. the pre-activations on the input side, so
  * db_ih is its column sum) and d_d_hgates float32[T][R][3H] (w.r.t. W_hh h + b_hh: dW_hh = d_hgates^T @ h_{t-1}
- * stacked over t, db_hh its column sum), optionally d_d_h0 float32[R][H]. */
+ * stacked over t, db_hh its column sum), optionally d_d_h0 float32[R][H].  When d_bias_part is non-NULL it receives
+ * float32[gru_seq_row_blocks(R)][6H]: per row block the column sums db_ih (3H) | db_hh (3H) over its rows and all steps;
+ * the caller adds the blocks (fixed order: deterministic). */
+int64_t gru_seq_row_blocks(int64_t R);
 int gru_seq_backward(const float *d_grad_hs, const float *d_gates, const float *d_hs, const float *d_h0, const float *d_w_hh,
-                     int T, int64_t R, int hidden, float *d_d_igates, float *d_d_hgates, float *d_d_h0, void *stream);
+                     int T, int64_t R, int hidden, float *d_d_igates, float *d_d_hgates, float *d_d_h0, float *d_bias_part,
+                     void *stream);
 int gru_last_hip_error(void);
 
 #ifdef __cplusplus

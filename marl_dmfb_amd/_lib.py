@@ -152,7 +152,9 @@ def crnn_ops():
     lib.crnn_conv9_backward_mfma.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
     lib.crnn_last_hip_error.argtypes = []
     lib.gru_seq_forward.argtypes = [vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, vp, vp, vp]
-    lib.gru_seq_backward.argtypes = [vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, vp, vp, vp, vp]
+    lib.gru_seq_backward.argtypes = [vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, vp, vp, vp, vp, vp]
+    lib.gru_seq_row_blocks.argtypes = [i64]
+    lib.gru_seq_row_blocks.restype = i64
     lib.gru_last_hip_error.argtypes = []
     lib._typed = True
     return lib

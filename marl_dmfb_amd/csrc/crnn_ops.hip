@@ -340,33 +340,45 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     if (tid >= kBlock - OD) pp[kBlock * 18 + OD + kBlock * 3 + (tid - (kBlock - OD))] = accB1;
 }
 
-// Sum of the partial vectors -> the four gradient tensors (tiny: <= 256 x ~11k floats), one thread per output.
+// Sum of the partial vectors -> the four gradient tensors (<= 256 x ~11k floats).  64 outputs per 256-thread
+// workgroup: thread (ty, tx) adds every 4th partial vector of output tx (independent loads in flight), the four
+// sub-sums meet in LDS in a fixed order (deterministic).
 template <int OD>
-__global__ void k_conv9_bwd_reduce(const float *__restrict__ part, int n_part, float *__restrict__ grads) {
+__global__ __launch_bounds__(256) void k_conv9_bwd_reduce(const float *__restrict__ part, int n_part, float *__restrict__ grads) {
     using G = GeoB<OD>;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_sum[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
     const int n2 = OD * OD * 9, nb = OD, n1 = OD * 27;
-    if (i >= n2 + nb + n1 + nb) return;
     float acc = 0.0f;
-    if (i < n2) {                                        // dW2[c2][c1][tap]
-        const int pair = i / 9, tap = i - pair * 9;
-        for (int b = 0; b < n_part; ++b) {
-            const float *pp = part + (size_t)b * G::PART;
-            if (pair < kBlock) acc += pp[pair * 9 + tap];
-            else if (G::EXTRA == kBlock) acc += pp[kBlock * 9 + (pair - kBlock) * 9 + tap];
+    if (i < n2 + nb + n1 + nb) {
+        // up to 8 source slots of output i inside one partial vector (offsets), all partial vectors share them
+        int off[8], cnt = 0;
+        if (i < n2) {                                        // dW2[c2][c1][tap]
+            const int pair = i / 9, tap = i - pair * 9;
+            if (pair < kBlock) off[cnt++] = pair * 9 + tap;
+            else if (G::EXTRA == kBlock) off[cnt++] = kBlock * 9 + (pair - kBlock) * 9 + tap;
             else
-                for (int sl = 0; sl < G::XSLICES; ++sl) acc += pp[kBlock * 9 + (sl * G::EXTRA + (pair - kBlock)) * 9 + tap];
+                for (int sl = 0; sl < G::XSLICES && sl < 8; ++sl) off[cnt++] = kBlock * 9 + (sl * G::EXTRA + (pair - kBlock)) * 9 + tap;
+        } else if (i < n2 + nb) {                            // db2
+            off[cnt++] = kBlock * 18 + (i - n2);
+        } else if (i < n2 + nb + n1) {                       // dW1[c1][c0][kx][ky]: item = (c1*3+c0)*3+kx, ky
+            const int jx = i - n2 - nb, item = jx / 3, ky = jx - item * 3;
+            for (int sl = 0; sl < G::RS3; ++sl) off[cnt++] = kBlock * 18 + OD + (sl * G::ITEMS3 + item) * 3 + ky;
+        } else {                                             // db1
+            off[cnt++] = kBlock * 18 + OD + kBlock * 3 + (i - n2 - nb - n1);
         }
-    } else if (i < n2 + nb) {                            // db2
-        for (int b = 0; b < n_part; ++b) acc += part[(size_t)b * G::PART + kBlock * 18 + (i - n2)];
-    } else if (i < n2 + nb + n1) {                       // dW1[c1][c0][kx][ky]: item = (c1*3+c0)*3+kx, ky
-        const int j = i - n2 - nb, item = j / 3, ky = j - item * 3;
-        for (int b = 0; b < n_part; ++b)
-            for (int sl = 0; sl < G::RS3; ++sl) acc += part[(size_t)b * G::PART + kBlock * 18 + OD + (sl * G::ITEMS3 + item) * 3 + ky];
-    } else {                                             // db1
-        for (int b = 0; b < n_part; ++b) acc += part[(size_t)b * G::PART + kBlock * 18 + OD + kBlock * 3 + (i - n2 - nb - n1)];
+        for (int k = 0; k < cnt; ++k) {
+            float a0 = 0.0f, a1 = 0.0f;
+            int b = ty;
+            for (; b + 4 < n_part; b += 8) { a0 += part[(size_t)b * G::PART + off[k]]; a1 += part[(size_t)(b + 4) * G::PART + off[k]]; }
+            if (b < n_part) a0 += part[(size_t)b * G::PART + off[k]];
+            acc += a0 + a1;
+        }
     }
-    grads[i] = acc;
+    s_sum[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && i < n2 + nb + n1 + nb) grads[i] = (s_sum[0][tx] + s_sum[1][tx]) + (s_sum[2][tx] + s_sum[3][tx]);
 }
 
 thread_local int g_last_hip = 0;
@@ -426,7 +438,7 @@ int launch_bwd(const int8_t *obs, long obs_stride, long rows, const float *a1_sa
     hipLaunchKernelGGL((k_conv9_bwd<OD>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, a1_save, a2, a2_stride, g, g_stride,
                        w2, part);
     const int n_out = OD * OD * 9 + OD + OD * 27 + OD;
-    hipLaunchKernelGGL((k_conv9_bwd_reduce<OD>), dim3((n_out + 255) / 256), dim3(256), 0, s, part, grid, grads);
+    hipLaunchKernelGGL((k_conv9_bwd_reduce<OD>), dim3((n_out + 63) / 64), dim3(256), 0, s, part, grid, grads);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
     return CRNN_OK;

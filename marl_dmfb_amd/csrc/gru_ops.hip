@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
                                                         const float *__restrict__ hs, const float *__restrict__ h0,
                                                         const float *__restrict__ w_hh, int T, long R,
                                                         float *__restrict__ d_ig, float *__restrict__ d_hg,
-                                                        float *__restrict__ d_h0) {
+                                                        float *__restrict__ d_h0, float *__restrict__ bias_part) {
     __shared__ __attribute__((aligned(16))) float s_dhg[RW][3][H];
     __shared__ __attribute__((aligned(16))) float s_part[4][RW][H];
     const int tid = threadIdx.x, q = tid / H, u = tid - q * H;
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
         for (int k = 0; k < KQ; ++k) wt[g][k] = w_hh[(size_t)(g * H + q * KQ + k) * H + u];
     const int ra = 2 * q;
     float gh[2] = {0.0f, 0.0f};  // dL/dh_t arriving from the future for my two (row, u) entries
+    float bs_r = 0.0f, bs_z = 0.0f, bs_n = 0.0f, bs_hn = 0.0f;  // column sums of the gate gradients (bias gradients)
     for (int t = T - 1; t >= 0; --t) {
         float direct[2];
 #pragma unroll
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
                 dpz = dz * zg * (1.0f - zg);
                 d_ig[o * 3 * H + u] = dpr; d_ig[o * 3 * H + H + u] = dpz; d_ig[o * 3 * H + 2 * H + u] = dpn;
                 d_hg[o * 3 * H + u] = dpr; d_hg[o * 3 * H + H + u] = dpz; d_hg[o * 3 * H + 2 * H + u] = dhn;
+                bs_r += dpr; bs_z += dpz; bs_n += dpn; bs_hn += dhn;
             }
             s_dhg[rr][0][u] = dpr; s_dhg[rr][1][u] = dpz; s_dhg[rr][2][u] = dhn;
         }
@@ -174,6 +176,19 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
 #pragma unroll
         for (int s = 0; s < 2; ++s)
             if (ra + s < rv) d_h0[(row0 + ra + s) * H + u] = gh[s];
+    if (bias_part) {  // this workgroup's share of db_ih (r|z|n) and db_hh (r|z|hn): the 4 row-pair threads of a unit meet in LDS
+        __syncthreads();
+        s_part[q][0][u] = bs_r; s_part[q][1][u] = bs_z; s_part[q][2][u] = bs_n; s_part[q][3][u] = bs_hn;
+        __syncthreads();
+        if (q == 0) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (s_part[0][k][u] + s_part[1][k][u]) + (s_part[2][k][u] + s_part[3][k][u]);
+            float *bp = bias_part + (size_t)blockIdx.x * 6 * H;
+            bp[u] = v[0]; bp[H + u] = v[1]; bp[2 * H + u] = v[2];
+            bp[3 * H + u] = v[0]; bp[4 * H + u] = v[1]; bp[5 * H + u] = v[3];
+        }
+    }
 }
 
 thread_local int g_last = 0;
@@ -196,17 +211,20 @@ int gru_seq_forward(const float *d_igates, const float *d_h0, const float *d_w_h
 }
 
 int gru_seq_backward(const float *d_grad_hs, const float *d_gates, const float *d_hs, const float *d_h0, const float *d_w_hh,
-                     int T, int64_t R, int hidden, float *d_d_igates, float *d_d_hgates, float *d_d_h0, void *stream) {
+                     int T, int64_t R, int hidden, float *d_d_igates, float *d_d_hgates, float *d_d_h0, float *d_bias_part,
+                     void *stream) {
     if (!d_grad_hs || !d_gates || !d_hs || !d_h0 || !d_w_hh || !d_d_igates || !d_d_hgates || T < 0 || R < 0) return CRNN_ERR_BAD_ARG;
     if (hidden != H) return CRNN_ERR_UNSUPPORTED;
     if (T == 0 || R == 0) return CRNN_OK;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_gru_seq_bwd, dim3((unsigned)((R + RW - 1) / RW)), dim3(kBlock), 0, (hipStream_t)stream, d_grad_hs, d_gates, d_hs,
-                       d_h0, d_w_hh, T, (long)R, d_d_igates, d_d_hgates, d_d_h0);
+                       d_h0, d_w_hh, T, (long)R, d_d_igates, d_d_hgates, d_d_h0, d_bias_part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last = (int)e; return CRNN_ERR_HIP; }
     return CRNN_OK;
 }
+
+int64_t gru_seq_row_blocks(int64_t R) { return (R + RW - 1) / RW; }
 
 int gru_last_hip_error(void) { return g_last; }
 

@@ -290,17 +290,19 @@ class _GRUSeqHip(torch.autograd.Function):
         d_ig = torch.empty((T, R, 3 * H), dtype=torch.float32, device=hs.device)
         d_hg = torch.empty_like(d_ig)
         d_h0 = torch.empty_like(h0c)
+        bias_part = torch.empty((lib.gru_seq_row_blocks(R), 6 * H), dtype=torch.float32, device=hs.device)
         vp = C.c_void_p
         rc = lib.gru_seq_backward(vp(grad_out.data_ptr()), vp(gates.data_ptr()), vp(hs.data_ptr()), vp(h0c.data_ptr()),
                                   vp(w.data_ptr()), T, R, H, vp(d_ig.data_ptr()), vp(d_hg.data_ptr()), vp(d_h0.data_ptr()),
-                                  vp(torch.cuda.current_stream(hs.device).cuda_stream))
+                                  vp(bias_part.data_ptr()), vp(torch.cuda.current_stream(hs.device).cuda_stream))
         if rc != 0:
             raise RuntimeError('gru_seq_backward failed: %d (hip %d)' % (rc, lib.gru_last_hip_error()))
         # dW_hh = sum_t d_hg[t]^T h_{t-1}: h_0 separately, the rest straight from the saved hs (no concatenated copy)
         d_w_hh = torch.matmul(d_hg[0].t(), h0c)
         if T > 1:
             d_w_hh = d_w_hh + _wgrad_splitk(d_hg[1:].reshape((T - 1) * R, 3 * H), hs[:-1].reshape((T - 1) * R, H))
-        return d_ig, d_h0, d_w_hh, d_ig.sum(dim=(0, 1)), d_hg.sum(dim=(0, 1))
+        d_b = bias_part.sum(0)  # per-row-block column sums from the kernel: db_ih | db_hh
+        return d_ig, d_h0, d_w_hh, d_b[:3 * H], d_b[3 * H:]
 
 
 def gru_sequence(igates, h0, w_hh, b_ih, b_hh, impl='hip'):

@@ -87,7 +87,7 @@ def test_crnn_ops_library_exports():
     assert names == ['crnn_conv9_a1_floats', 'crnn_conv9_backward', 'crnn_conv9_backward_mfma', 'crnn_conv9_backward_mfma_parts', 'crnn_conv9_backward_parts', 'crnn_conv9_forward', 'crnn_conv9_forward_train',
                      'crnn_front9_forward', 'crnn_front9_forward_train', 'crnn_last_hip_error']
     gru = sorted(set(re.findall(r'\b(gru_[a-z_0-9]+)\s*\(', txt)))
-    assert gru == ['gru_last_hip_error', 'gru_seq_backward', 'gru_seq_forward']
+    assert gru == ['gru_last_hip_error', 'gru_seq_backward', 'gru_seq_forward', 'gru_seq_row_blocks']
     for n in names + gru:
         assert hasattr(lib, n)
     # argument guards run on the host before anything touches the GPU
