@@ -57,7 +57,13 @@ int crnn_conv9_a1_floats(int od);
 int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_a1_save, const float *d_out,
                         int64_t out_stride, const float *d_grad_out, int64_t grad_stride, const float *d_w2, int od,
                         float *d_part, int n_part, float *d_grads, void *stream);
-/* The same gradients WITHOUT saved activations: conv1 is recomputed per row block on the matrix cores, the three
+/* crnn_conv9_backward without d_a1_save: the conv1 activations of each row block are recomputed inside the kernel (f32
+ * MFMA, as the forward computes them) and the next block's inputs are prefetched while the current one is reduced; used
+ * with crnn_front9_forward / crnn_conv9_forward (nothing saved).  d_part as crnn_conv9_backward. */
+int crnn_conv9_backward_rc(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
+                           const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1, const float *d_w2,
+                           int od, float *d_part, int n_part, float *d_grads, void *stream);
+/* Experimental: the same gradients with all three contractions on MFMA: conv1 is recomputed per row block on the matrix cores, the three
  * gradient contractions run as f32 MFMA GEMMs (csrc/crnn_mfma_bwd.h).  d_out / d_grad_out as above;
  * d_part float32[n_part][crnn_conv9_backward_mfma_parts(od)] scratch (n_part <= 256). */
 int crnn_conv9_backward_mfma_parts(int od);

@@ -148,6 +148,7 @@ def crnn_ops():
     lib.crnn_conv9_backward_parts.argtypes = [C.c_int]
     lib.crnn_conv9_a1_floats.argtypes = [C.c_int]
     lib.crnn_conv9_backward.argtypes = [vp, i64, i64, vp, vp, i64, vp, i64, vp, C.c_int, vp, C.c_int, vp, vp]
+    lib.crnn_conv9_backward_rc.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
     lib.crnn_conv9_backward_mfma_parts.argtypes = [C.c_int]
     lib.crnn_conv9_backward_mfma.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
     lib.crnn_last_hip_error.argtypes = []

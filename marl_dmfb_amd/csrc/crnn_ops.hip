@@ -183,11 +183,15 @@ template <int OD> struct GeoB {
     static constexpr int PART = kBlock * 9 + kBlock * 9 + OD + kBlock * 3 + OD;
 };
 
-template <int OD>
+// RC = true: nothing was saved by the forward; the conv1 activations of each row block are recomputed on the matrix
+// cores (the forward's f32 MFMA tiling, crnn_mfma.h) and the next block's dz2 / pixel rows are fetched into registers
+// while phase P3 runs, so no HBM latency sits between two barriers.  RC = false: a1 comes from a1_save.
+template <int OD, bool RC>
 __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__ obs, long obs_stride, long rows,
                                                       const float *__restrict__ a1_save, const float *__restrict__ a2,
                                                       long a2_stride, const float *__restrict__ g, long g_stride,
-                                                      const float *__restrict__ w2, float *__restrict__ part) {
+                                                      const float *__restrict__ w2, float *__restrict__ part,
+                                                      const float *__restrict__ w1, const float *__restrict__ b1) {
     using G = GeoB<OD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *s_w2 = lds;                                  // [c2][tap][c1]
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         const int c2 = i / (OD * 9), rem = i - c2 * OD * 9, c1 = rem / 9, tap = rem - c1 * 9;
         s_w2[(c2 * 9 + tap) * OD + c1] = w2[i];
     }
-    float accA[9], accX[9], accW1[3], accB2 = 0.0f, accB1 = 0.0f;  // persistent over all rows of the workgroup
+    float accA[9], accX[9], accW1[3], accB2 = 0.0f, accB2x = 0.0f, accB1 = 0.0f;  // persistent over all rows of the workgroup
 #pragma unroll
     for (int k = 0; k < 9; ++k) { accA[k] = 0.0f; accX[k] = 0.0f; }
 #pragma unroll
@@ -219,28 +223,123 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     const long n_blocks = (rows + G::RBB - 1) / G::RBB;
     const long per = (n_blocks + gridDim.x - 1) / gridDim.x;
     const long blk0 = (long)blockIdx.x * per, blk1 = min(n_blocks, blk0 + per);
+
+    // ---- RC: conv1 roles (wave = (channel half, row residue)), B operands, prefetch registers
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, wave = tid >> 6, j16 = lane & 15, kq = lane >> 4;
+    const int c_nh = (wave >> 1) & 1, c_sub = (wave & 1) + 2 * (wave >> 2), c_ch = c_nh * 16 + j16;
+    const bool c_chv = c_ch < OD;
+    constexpr int NPD = (G::RBB * OD * 25 + kBlock - 1) / kBlock, NPI = (G::RBB * 243 + kBlock - 1) / kBlock;
+    float pfd[RC ? NPD : 1], pfi[RC ? NPI : 1];
+    auto fetch = [&](long b) {
+        const long r0 = b * G::RBB;
+        const int rvb = b < blk1 ? (int)min((long)G::RBB, rows - r0) : 0;
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));  // opaque: keeps the index arithmetic below out of the loop-invariant registers
+#pragma unroll
+        for (int u = 0; u < NPD; ++u) {
+            const int i = t_ + u * kBlock, rr = i / (OD * 25), rem = i - rr * OD * 25;
+            float v = 0.0f;
+            if (i < G::RBB * OD * 25 && rr < rvb) {
+                const float act = a2[(r0 + rr) * a2_stride + rem];
+                const float gv = g[(r0 + rr) * g_stride + rem];
+                v = act > 0.0f ? gv : 0.0f;
+            }
+            pfd[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NPI; ++u) {
+            const int i = t_ + u * kBlock, rr = i / 243, pp = i - rr * 243;
+            pfi[u] = (i < G::RBB * 243 && rr < rvb) ? (float)obs[(r0 + rr) * obs_stride + pp] : 0.0f;
+        }
+    };
+    if constexpr (RC) fetch(blk0);
     for (long blk = blk0; blk < blk1; ++blk) {
         const long row0 = blk * G::RBB;
         const int rv = (int)min((long)G::RBB, rows - row0);
         __syncthreads();
-        // ---- P0: stage the rows (a1 is saved in the padded LDS layout: straight 16-byte copies)
-        {
-            const float4 *src = (const float4 *)(a1_save + row0 * OD * kA1Stride);
-            float4 *dst = (float4 *)s_a1;
-            for (int i = tid; i < rv * OD * kA1Stride / 4; i += kBlock) dst[i] = src[i];
-        }
-        for (int i = tid; i < rv * OD * 25; i += kBlock) {
-            const int rr = i / (OD * 25), rem = i - rr * OD * 25, c = rem / 25, k = rem - c * 25;
-            const float act = a2[(row0 + rr) * a2_stride + rem];
-            s_dz2[(rr * OD + c) * G::DZ2 + k] = act > 0.0f ? g[(row0 + rr) * g_stride + rem] : 0.0f;
-        }
-        for (int i = tid; i < rv * 243; i += kBlock) {
-            const int rr = i / 243, pp = i - rr * 243;
-            s_in[rr * 244 + pp] = (float)obs[(row0 + rr) * obs_stride + pp];
+        if constexpr (RC) {
+            // ---- P0 (RC): park the prefetched rows, then conv1 + ReLU on MFMA into s_a1 ([row][c][52])
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+#pragma unroll
+            for (int u = 0; u < NPD; ++u) {
+                const int i = t_ + u * kBlock, rc = i / 25, k = i - rc * 25;
+                if (i < G::RBB * OD * 25) s_dz2[rc * G::DZ2 + k] = pfd[u];
+            }
+#pragma unroll
+            for (int u = 0; u < NPI; ++u) {
+                const int i = t_ + u * kBlock, rr = i / 243, pp = i - rr * 243;
+                if (i < G::RBB * 243) s_in[rr * 244 + pp] = pfi[u];
+            }
+            __syncthreads();
+            // the conv1 B operands are re-read from L2 every block: nothing of this phase stays in registers
+            // while the gradient phases run at the register limit
+            int off1[7], goff[3];
+            float bw1[7];
+            int kq_ = kq, j_ = j16;
+            asm volatile("" : "+v"(kq_), "+v"(j_));
+#pragma unroll
+            for (int s = 0; s < 7; ++s) {
+                const int k = 4 * s + kq_, c0 = k / 9, tap = k - c0 * 9;
+                off1[s] = k < 27 ? c0 * 81 + (tap / 3) * 9 + tap % 3 : 0;
+                bw1[s] = (c_chv && k < 27) ? w1[c_ch * 27 + k] : 0.0f;
+            }
+            const float c_bias = c_chv ? b1[c_ch] : 0.0f;
+#pragma unroll
+            for (int qt = 0; qt < 3; ++qt) { const int p = qt * 16 + j_; goff[qt] = (p / 7) * 9 + p % 7; }
+            for (int rr = c_sub; rr < G::RBB; rr += 4) {
+                float cv[3][7];
+#pragma unroll
+                for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+                    for (int s = 0; s < 7; ++s) cv[qt][s] = s_in[rr * 244 + goff[qt] + off1[s]];
+                f32x4 acc[3];
+#pragma unroll
+                for (int qt = 0; qt < 3; ++qt) acc[qt] = f32x4{c_bias, c_bias, c_bias, c_bias};
+#pragma unroll
+                for (int s = 0; s < 7; ++s)
+#pragma unroll
+                    for (int qt = 0; qt < 3; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[qt][s], bw1[s], acc[qt], 0, 0, 0);
+                if (c_chv) {
+                    float *dst = s_a1 + (rr * OD + c_ch) * kA1Stride + kq * 4;
+#pragma unroll
+                    for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dst[qt * 16 + q] = fmaxf(acc[qt][q], 0.0f);
+                }
+            }
+            if (c_sub == 0) {  // position 48 of every row: lane i gathers row i
+                const int rr = j16 < G::RBB ? j16 : G::RBB - 1;
+                f32x4 acc = {c_bias, c_bias, c_bias, c_bias};
+#pragma unroll
+                for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s_in[rr * 244 + 60 + off1[s]], bw1[s], acc, 0, 0, 0);
+                if (c_chv) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (kq * 4 + q < G::RBB) s_a1[((kq * 4 + q) * OD + c_ch) * kA1Stride + 48] = fmaxf(acc[q], 0.0f);
+                }
+            }
+        } else {
+            // ---- P0: stage the rows (a1 is saved in the padded LDS layout: straight 16-byte copies)
+            {
+                const float4 *src = (const float4 *)(a1_save + row0 * OD * kA1Stride);
+                float4 *dst = (float4 *)s_a1;
+                for (int i = tid; i < rv * OD * kA1Stride / 4; i += kBlock) dst[i] = src[i];
+            }
+            for (int i = tid; i < rv * OD * 25; i += kBlock) {
+                const int rr = i / (OD * 25), rem = i - rr * OD * 25, c = rem / 25, k = rem - c * 25;
+                const float act = a2[(row0 + rr) * a2_stride + rem];
+                s_dz2[(rr * OD + c) * G::DZ2 + k] = act > 0.0f ? g[(row0 + rr) * g_stride + rem] : 0.0f;
+            }
+            for (int i = tid; i < rv * 243; i += kBlock) {
+                const int rr = i / 243, pp = i - rr * 243;
+                s_in[rr * 244 + pp] = (float)obs[(row0 + rr) * obs_stride + pp];
+            }
         }
         __syncthreads();
         // ---- P1: dW2 (and db2)
-        auto pair_rows = [&](int c2, int c1, int r_begin, int r_step, float (&acc)[9]) {
+        auto pair_rows = [&](int c2, int c1, int r_begin, int r_step, float (&acc)[9], float *sum_dz) {
             for (int rr = r_begin; rr < rv; rr += r_step) {
                 float dz[G::DZ2], a[kA1Stride];
                 const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + (rr * OD + c2) * G::DZ2, 16);
@@ -258,17 +357,26 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
 #pragma unroll
                             for (int y = 0; y < 5; ++y)
                                 acc[kx * 3 + ky] = fmaf(dz[x * 5 + y], a[(x + kx) * 7 + y + ky], acc[kx * 3 + ky]);
+                if (sum_dz) {  // db2[c2]: the thread of pair (c2, 0) already holds this row's dz2 in registers
+                    float t = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 25; ++k) t += dz[k];
+                    *sum_dz += t;
+                }
             }
         };
-        if (pa_on) pair_rows(pa_c2, pa_c1, 0, 1, accA);
-        if (px_on) pair_rows(px_c2, px_c1, px_slice, (G::EXTRA == kBlock) ? 1 : G::XSLICES, accX);
-        if (tid < OD)
-            for (int rr = 0; rr < rv; ++rr)
-                for (int k = 0; k < 25; ++k) accB2 += s_dz2[(rr * OD + tid) * G::DZ2 + k];
+#ifndef CRNN_PROBE_SKIP_P1
+        if (pa_on) pair_rows(pa_c2, pa_c1, 0, 1, accA, pa_c1 == 0 ? &accB2 : nullptr);
+        if (px_on) pair_rows(px_c2, px_c1, px_slice, (G::EXTRA == kBlock) ? 1 : G::XSLICES, accX, px_c1 == 0 ? &accB2x : nullptr);
+#endif
         // ---- P2: da1 partial sums over half of the c2 range; half 1 parks its partial in s_dz1
         const int half = tid / (G::RBB * OD), rem2 = tid - half * G::RBB * OD;
         const int r2 = rem2 / OD, c1b = rem2 - r2 * OD;
+#ifndef CRNN_PROBE_SKIP_P2
         const bool p2 = half < 2 && r2 < rv;
+#else
+        const bool p2 = false;
+#endif
         float da[49];
         if (p2) {
 #pragma unroll
@@ -305,8 +413,13 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
             for (int k = 0; k < 49; ++k) dst[k] = act[k] > 0.0f ? da[k] + dst[k] : 0.0f;
         }
         __syncthreads();
+        if constexpr (RC) fetch(blk + 1);  // lands while P3 runs; parked after the next barrier
         // ---- P3: dW1[c1][c0][kx][0..2] over this thread's row slice (and db1)
+#ifdef CRNN_PROBE_SKIP_P3
+        if (false) {
+#else
         if (p3_on) {
+#endif
             for (int rr = s3; rr < rv; rr += G::RS3) {
                 float dz[kA1Stride];
                 const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz1 + (rr * OD + c1_3) * kA1Stride, 16);
@@ -323,21 +436,37 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
 #pragma unroll
                         for (int y = 0; y < 7; ++y) accW1[ky] = fmaf(dz[x * 7 + y], v[y + ky], accW1[ky]);
                 }
+                if (c0_3 == 0 && kx_3 == 0) {  // db1[c1] over this thread's row slice: dz1 is in registers
+                    float t = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 49; ++k) t += dz[k];
+                    accB1 += t;
+                }
             }
         }
-        if (tid >= kBlock - OD) {
-            const int c1 = tid - (kBlock - OD);
-            for (int rr = 0; rr < rv; ++rr)
-                for (int k = 0; k < 49; ++k) accB1 += s_dz1[(rr * OD + c1) * kA1Stride + k];
-        }
     }
+    // bias gradients: db1's RS3 (<= 2) row slices of a channel meet in LDS (two adds into zero: order-independent);
+    // db2[c2] sits with the thread of pair (c2, 0) -- first pass, or up to 8 row slices of the extra pass -- and is
+    // summed slot by slot in a fixed order
+    __syncthreads();
+    for (int i = tid; i < 64 + OD * 8; i += kBlock) s_dz2[i] = 0.0f;
+    __syncthreads();
+    if (p3_on && c0_3 == 0 && kx_3 == 0) atomicAdd(&s_dz2[c1_3], accB1);
+    if (pa_on && pa_c1 == 0) s_dz2[64 + pa_c2 * 8] = accB2;
+    if (px_on && px_c1 == 0) s_dz2[64 + px_c2 * 8 + (px_slice & 7)] = accB2x;
+    __syncthreads();
     float *pp = part + (size_t)blockIdx.x * G::PART;
 #pragma unroll
     for (int k = 0; k < 9; ++k) { pp[tid * 9 + k] = accA[k]; pp[kBlock * 9 + tid * 9 + k] = accX[k]; }
-    if (tid < OD) pp[kBlock * 18 + tid] = accB2;
+    if (tid < OD) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s_dz2[64 + tid * 8 + k];
+        pp[kBlock * 18 + tid] = t;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) pp[kBlock * 18 + OD + tid * 3 + k] = accW1[k];
-    if (tid >= kBlock - OD) pp[kBlock * 18 + OD + kBlock * 3 + (tid - (kBlock - OD))] = accB1;
+    if (tid < OD) pp[kBlock * 18 + OD + kBlock * 3 + tid] = s_dz2[tid];
 }
 
 // Sum of the partial vectors -> the four gradient tensors (<= 256 x ~11k floats).  64 outputs per 256-thread
@@ -423,20 +552,21 @@ int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const
 }
 
 
-template <int OD>
+template <int OD, bool RC>
 int launch_bwd(const int8_t *obs, long obs_stride, long rows, const float *a1_save, const float *a2, long a2_stride,
-               const float *g, long g_stride, const float *w2, float *part, int grid, float *grads, hipStream_t s) {
+               const float *g, long g_stride, const float *w2, float *part, int grid, float *grads, const float *w1, const float *b1,
+               hipStream_t s) {
     using G = GeoB<OD>;
     const size_t lds = G::LDS_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv9_bwd<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv9_bwd<OD, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
         attr_set = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_conv9_bwd<OD>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, a1_save, a2, a2_stride, g, g_stride,
-                       w2, part);
+    hipLaunchKernelGGL((k_conv9_bwd<OD, RC>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, a1_save, a2, a2_stride, g, g_stride,
+                       w2, part, w1, b1);
     const int n_out = OD * OD * 9 + OD + OD * 27 + OD;
     hipLaunchKernelGGL((k_conv9_bwd_reduce<OD>), dim3((n_out + 63) / 64), dim3(256), 0, s, part, grid, grads);
     hipError_t e = hipGetLastError();
@@ -521,8 +651,19 @@ int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, c
                         float *d_part, int n_part, float *d_grads, void *stream) {
     if (!d_obs || !d_a1_save || !d_out || !d_grad_out || !d_w2 || !d_part || !d_grads || rows <= 0 || n_part < 1 || n_part > 256)
         return CRNN_ERR_BAD_ARG;
-    if (od == 24) return launch_bwd<24>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, (hipStream_t)stream);
-    if (od == 32) return launch_bwd<32>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, (hipStream_t)stream);
+    if (od == 24) return launch_bwd<24, false>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, nullptr, nullptr, (hipStream_t)stream);
+    if (od == 32) return launch_bwd<32, false>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, nullptr, nullptr, (hipStream_t)stream);
+    return CRNN_ERR_UNSUPPORTED;
+}
+
+int crnn_conv9_backward_rc(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
+                           const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1, const float *d_w2,
+                           int od, float *d_part, int n_part, float *d_grads, void *stream) {
+    if (!d_obs || !d_out || !d_grad_out || !d_w1 || !d_b1 || !d_w2 || !d_part || !d_grads || rows <= 0 || n_part < 1 || n_part > 256 ||
+        obs_stride < 243 || out_stride < od * 25 || grad_stride < od * 25)
+        return CRNN_ERR_BAD_ARG;
+    if (od == 24) return launch_bwd<24, true>(d_obs, obs_stride, rows, nullptr, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, d_w1, d_b1, (hipStream_t)stream);
+    if (od == 32) return launch_bwd<32, true>(d_obs, obs_stride, rows, nullptr, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, d_w1, d_b1, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
 }
 

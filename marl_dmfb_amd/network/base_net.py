@@ -98,12 +98,16 @@ class _ConvFront9(torch.autograd.Function):
         return None, g_w1, g_b1, g_w2, g_b2
 
 
-def _conv_bwd_mfma():
-    """CRNN_CONV_BWD=mfma selects the matrix-core backward that recomputes conv1 (csrc/crnn_mfma_bwd.h; correct, but its
-    col2im phase scatters through LDS float atomics and is 2x slower than the VALU kernel: 3.2 vs 1.65 ms per 81920
-    rows on MI355X).  Default: the VALU backward kernel, which reads the conv1 activations saved by the forward."""
+def _conv_bwd_mode():
+    """Backward kernel of the conv front end, CRNN_CONV_BWD = rc | valu | mfma:
+    rc (default)  VALU gradient kernel that recomputes conv1 on the matrix cores and prefetches the next row block
+                  (crnn_conv9_backward_rc); the forward saves nothing;
+    valu          the same kernel reading the conv1 activations saved by crnn_front9_forward_train;
+    mfma          all three contractions on MFMA (csrc/crnn_mfma_bwd.h; correct, but its col2im phase scatters through
+                  LDS float atomics: 3.2 ms per 81920 rows vs 1.6 ms for valu on MI355X)."""
     import os
-    return os.environ.get('CRNN_CONV_BWD', 'valu') == 'mfma'
+    m = os.environ.get('CRNN_CONV_BWD', 'rc')
+    return m if m in ('rc', 'valu', 'mfma') else 'rc'
 
 
 class _Front9Train(torch.autograd.Function):
@@ -122,8 +126,8 @@ class _Front9Train(torch.autograd.Function):
         x = torch.empty((R, od * 25 + 10), dtype=torch.float32, device=obs_i8.device)
         w1c, b1c, w2c, b2c, mwc, mbc = (t.detach().contiguous() for t in (w1, b1, w2, b2, mlp_w, mlp_b))
         stream = vp(torch.cuda.current_stream(obs_i8.device).cuda_stream)
-        ctx.mfma = _conv_bwd_mfma()
-        if ctx.mfma:
+        ctx.mode = _conv_bwd_mode()
+        if ctx.mode != 'valu':
             a1 = w1c  # placeholder: nothing is saved, the backward recomputes conv1
             rc = lib.crnn_front9_forward(vp(obs_i8.data_ptr()), obs_i8.stride(0), vp(onehot_i8.data_ptr()), A, R, vp(w1c.data_ptr()),
                                          vp(b1c.data_ptr()), vp(w2c.data_ptr()), vp(b2c.data_ptr()), vp(mwc.data_ptr()),
@@ -154,7 +158,13 @@ class _Front9Train(torch.autograd.Function):
         n2 = od * od * 9
         tot = torch.empty(n2 + od + od * 27 + od, dtype=torch.float32, device=g.device)
         stream = vp(torch.cuda.current_stream(g.device).cuda_stream)
-        if ctx.mfma:
+        if ctx.mode == 'rc':
+            part = torch.empty((_ConvFront9.N_PART, lib.crnn_conv9_backward_parts(od)), dtype=torch.float32, device=g.device)
+            rc = lib.crnn_conv9_backward_rc(vp(obs_i8.data_ptr()), obs_i8.stride(0), R, vp(x.data_ptr()), x.stride(0),
+                                            vp(g.data_ptr()), g.stride(0), vp(w1c.data_ptr()), vp(b1c.data_ptr()),
+                                            vp(w2c.data_ptr()), od, vp(part.data_ptr()), _ConvFront9.N_PART, vp(tot.data_ptr()),
+                                            stream)
+        elif ctx.mode == 'mfma':
             part = torch.empty((_ConvFront9.N_PART, lib.crnn_conv9_backward_mfma_parts(od)), dtype=torch.float32, device=g.device)
             rc = lib.crnn_conv9_backward_mfma(vp(obs_i8.data_ptr()), obs_i8.stride(0), R, vp(x.data_ptr()), x.stride(0),
                                               vp(g.data_ptr()), g.stride(0), vp(w1c.data_ptr()), vp(b1c.data_ptr()),

@@ -135,8 +135,8 @@ def test_recurrent_seq_hip_equals_aten_path():
         assert torch.linalg.norm(g1 - g2) <= 1e-4 * torch.linalg.norm(g2)
 
 
-@pytest.mark.parametrize('bwd', ['valu', 'mfma'])
-@pytest.mark.parametrize('od,rows', [(24, 20000), (32, 5003), (24, 11), (24, 8)])
+@pytest.mark.parametrize('bwd', ['rc', 'valu', 'mfma'])
+@pytest.mark.parametrize('od,rows', [(24, 20000), (32, 5003), (24, 11), (24, 8), (24, 2563)])
 def test_front9_train_node_matches_torch_autograd(od, rows, bwd, monkeypatch):
     """_Front9Train (fused forward incl. mlp1; VALU backward on saved activations, or the MFMA backward that recomputes
     conv1) against float64 torch autograd of the reference network's front end (network/base_net.py:59-68).  Same
