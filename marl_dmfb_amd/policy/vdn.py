@@ -76,7 +76,9 @@ class VDN:
         elif args.optimizer == 'SGD':
             self.optimizer = torch.optim.SGD(self.eval_parameters, lr=args.lr)
         elif args.optimizer == 'ADAM':
-            self.optimizer = torch.optim.Adam(self.eval_parameters, lr=args.lr, betas=(0.9, 0.99))
+            # same update rule; on the GPU all parameter tensors are stepped by ONE fused kernel instead of ~8 foreach launches
+            fused = {'fused': True} if self.device.type == 'cuda' else {}
+            self.optimizer = torch.optim.Adam(self.eval_parameters, lr=args.lr, betas=(0.9, 0.99), **fused)
         elif args.optimizer == 'ASGD':
             self.optimizer = torch.optim.Adam(self.eval_parameters, lr=args.lr)
         else:
