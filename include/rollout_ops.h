@@ -35,6 +35,17 @@ int rollout_select_actions(const float *d_q, int32_t n_envs, int32_t n_agents, i
                            int32_t evaluate, uint64_t seed, const uint32_t *d_draw, int32_t *d_actions, int8_t *d_last_onehot,
                            int8_t *d_ep_u, int8_t *d_ep_onehot, int32_t episode_limit, int32_t t, void *stream);
 
+/* The tail of the per-step Q-network (network/base_net.py:69-70: GRUCell gate math + fc1) fused with the pick above: given
+ * d_igates = x W_ih^T and d_hgates = h W_hh^T (float32[E*n][3H], no bias, gate order r|z|n: the two GEMMs stay in the BLAS
+ * library) it computes h' = GRUCell(...) in place in d_h (float32[E*n][H]), q = fc1(h') (d_fc_w float32[A][H], d_fc_b [A];
+ * A <= 16; optionally written to d_q float32[E*n][A]) and then exactly rollout_select_actions on q.  hidden must be 128
+ * (ROLLOUT_ERR_BAD_ARG otherwise: use the BLAS + rollout_select_actions path). */
+int rollout_gru_head_select(const float *d_igates, const float *d_hgates, const float *d_b_ih, const float *d_b_hh, float *d_h,
+                            const float *d_fc_w, const float *d_fc_b, int32_t n_envs, int32_t n_agents, int32_t hidden,
+                            int32_t n_actions, const float *d_epsilon, int32_t evaluate, uint64_t seed, const uint32_t *d_draw,
+                            int32_t *d_actions, int8_t *d_last_onehot, int8_t *d_ep_u, int8_t *d_ep_onehot, int32_t episode_limit,
+                            int32_t t, float *d_q, void *stream);
+
 /* After the transition of lock-step t (rollout.py:118-129) for every chip e, with a = d_alive[e] BEFORE the step:
  *   r[e][t] = team_reward[e]; padded[e][t] = !a; terminated[e][t] = term[e]       (episode pointers may be NULL)
  *   sum_reward[e] += team_reward[e]; sum_constraints[e] += constraints[e]; sum_success[e] += success[e];

@@ -35,6 +35,7 @@ class Evaluator:
         self.use_graph = False
         self._graphs = {}
         self._rollout_lib = None
+        self.fuse_tail = True  # GRU gate math + fc1 + epsilon-greedy as one kernel when the Q-net is the fov-9 CRNN
         # key of the epsilon-greedy Philox stream: the env seed, shifted per shard so that ranks draw different numbers
         self.rng_seed = (int(getattr(env, 'seed', 0)) * 0x9E3779B97F4A7C15 + int(getattr(env, 'env_id0', 0)) + 0x600) & 0xFFFFFFFFFFFFFFFF
 
@@ -124,15 +125,27 @@ class Evaluator:
             p_pad, p_term = vp(ep['padded'].data_ptr()), vp(ep['terminated'].data_ptr())
             ep['o'][:, 0] = obs
         net = self.agents.policy.eval_rnn
+        fused_tail = (self.fuse_tail and hasattr(net, 'act_ok') and net.act_ok(obs.reshape(E * n, -1)) and hidden.is_contiguous()
+                      and hidden.dtype == torch.float32 and hidden.shape[1] == 128 and net.fc1.weight.is_contiguous())
         t_played = 0
         for t in range(T):
-            q, hidden = net.forward_obs(obs.reshape(E * n, -1), last_action.reshape(E * n, -1), hidden)
-            q = q.contiguous()
-            rc = lib.rollout_select_actions(vp(q.data_ptr()), E, n, A, vp(eps.data_ptr()), int(bool(evaluate)), self.rng_seed,
-                                            vp(self._draw.data_ptr()), vp(actions.data_ptr()), vp(last_action.data_ptr()),
-                                            p_u, p_oh, T, t, stream)
+            obs2, la2 = obs.reshape(E * n, -1), last_action.reshape(E * n, -1)
+            if fused_tail:
+                # front end + the two GRU GEMMs, then gate math + fc1 + epsilon-greedy in one launch (h updated in place)
+                ig, hg = net.act_gates(obs2, la2, hidden)
+                rc = lib.rollout_gru_head_select(vp(ig.data_ptr()), vp(hg.data_ptr()), vp(net.rnn.bias_ih.data_ptr()),
+                                                 vp(net.rnn.bias_hh.data_ptr()), vp(hidden.data_ptr()), vp(net.fc1.weight.data_ptr()),
+                                                 vp(net.fc1.bias.data_ptr()), E, n, hidden.shape[1], A, vp(eps.data_ptr()),
+                                                 int(bool(evaluate)), self.rng_seed, vp(self._draw.data_ptr()),
+                                                 vp(actions.data_ptr()), vp(last_action.data_ptr()), p_u, p_oh, T, t, null, stream)
+            else:
+                q, hidden = net.forward_obs(obs2, la2, hidden)
+                q = q.contiguous()
+                rc = lib.rollout_select_actions(vp(q.data_ptr()), E, n, A, vp(eps.data_ptr()), int(bool(evaluate)), self.rng_seed,
+                                                vp(self._draw.data_ptr()), vp(actions.data_ptr()), vp(last_action.data_ptr()),
+                                                p_u, p_oh, T, t, stream)
             if rc != 0:
-                raise RuntimeError('rollout_select_actions failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
+                raise RuntimeError('rollout action selection failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
             # frozen chips are not stepped: the kernel reports reward 0 / constraints 0 / success 0 / terminated 1
             obs, _, _, info = self.env.step(actions, active=alive, record=True)
             if record:  # frozen chips (alive == 0 before this step) keep zero rows: the padding rule of rollout.py:131-141

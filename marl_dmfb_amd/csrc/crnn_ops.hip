@@ -469,13 +469,14 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     if (tid < OD) pp[kBlock * 18 + OD + kBlock * 3 + tid] = s_dz2[tid];
 }
 
-// Sum of the partial vectors -> the four gradient tensors (<= 256 x ~11k floats).  64 outputs per 256-thread
-// workgroup: thread (ty, tx) adds every 4th partial vector of output tx (independent loads in flight), the four
+// Sum of the partial vectors -> the four gradient tensors (<= 256 x ~11k floats).  64 outputs per 1024-thread
+// workgroup: thread (ty, tx) adds every 16th partial vector of output tx (independent loads in flight), the 16
 // sub-sums meet in LDS in a fixed order (deterministic).
+constexpr int kRedY = 16;
 template <int OD>
-__global__ __launch_bounds__(256) void k_conv9_bwd_reduce(const float *__restrict__ part, int n_part, float *__restrict__ grads) {
+__global__ __launch_bounds__(64 * kRedY) void k_conv9_bwd_reduce(const float *__restrict__ part, int n_part, float *__restrict__ grads) {
     using G = GeoB<OD>;
-    __shared__ float s_sum[4][64];
+    __shared__ float s_sum[kRedY][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + tx;
     const int n2 = OD * OD * 9, nb = OD, n1 = OD * 27;
@@ -500,14 +501,19 @@ __global__ __launch_bounds__(256) void k_conv9_bwd_reduce(const float *__restric
         for (int k = 0; k < cnt; ++k) {
             float a0 = 0.0f, a1 = 0.0f;
             int b = ty;
-            for (; b + 4 < n_part; b += 8) { a0 += part[(size_t)b * G::PART + off[k]]; a1 += part[(size_t)(b + 4) * G::PART + off[k]]; }
+            for (; b + kRedY < n_part; b += 2 * kRedY) { a0 += part[(size_t)b * G::PART + off[k]]; a1 += part[(size_t)(b + kRedY) * G::PART + off[k]]; }
             if (b < n_part) a0 += part[(size_t)b * G::PART + off[k]];
             acc += a0 + a1;
         }
     }
     s_sum[ty][tx] = acc;
     __syncthreads();
-    if (ty == 0 && i < n2 + nb + n1 + nb) grads[i] = (s_sum[0][tx] + s_sum[1][tx]) + (s_sum[2][tx] + s_sum[3][tx]);
+    if (ty == 0 && i < n2 + nb + n1 + nb) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kRedY; ++k) t += s_sum[k][tx];
+        grads[i] = t;
+    }
 }
 
 thread_local int g_last_hip = 0;
@@ -568,7 +574,7 @@ int launch_bwd(const int8_t *obs, long obs_stride, long rows, const float *a1_sa
     hipLaunchKernelGGL((k_conv9_bwd<OD, RC>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, a1_save, a2, a2_stride, g, g_stride,
                        w2, part, w1, b1);
     const int n_out = OD * OD * 9 + OD + OD * 27 + OD;
-    hipLaunchKernelGGL((k_conv9_bwd_reduce<OD>), dim3((n_out + 63) / 64), dim3(256), 0, s, part, grid, grads);
+    hipLaunchKernelGGL((k_conv9_bwd_reduce<OD>), dim3((n_out + 63) / 64), dim3(64 * kRedY), 0, s, part, grid, grads);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
     return CRNN_OK;

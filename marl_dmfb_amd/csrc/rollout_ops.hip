@@ -54,6 +54,78 @@ __global__ void k_select(const float *__restrict__ q, int rows, int n, int A, co
     }
 }
 
+// GRU gate math (the formulas of aten's fused cell: hy = n + z (h - n)) + the Q head + the epsilon-greedy pick.  Hidden
+// size 128: half a wave per (chip, droplet) row, lane l of the half owns units 4l..4l+3 (16-byte loads of the six gate
+// pre-activations, h and the head weights); the head's dot products are 32-lane butterfly reductions.
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void k_gru_head_select(const float *__restrict__ ig, const float *__restrict__ hg, const float *__restrict__ b_ih,
+                                                         const float *__restrict__ b_hh, float *__restrict__ h, const float *__restrict__ fc_w,
+                                                         const float *__restrict__ fc_b, int rows, int n, int A,
+                                                         const float *__restrict__ eps_p, int evaluate, uint32_t k0, uint32_t k1,
+                                                         const uint32_t *__restrict__ draw_p, int32_t *__restrict__ actions,
+                                                         int8_t *__restrict__ last_onehot, int8_t *__restrict__ ep_u, int8_t *__restrict__ ep_onehot,
+                                                         int T, int t, float *__restrict__ q_out) {
+    constexpr int H = 128;
+    const int l32 = threadIdx.x & 31;
+    const int r = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool live = r < rows;
+    const int rc = live ? r : rows - 1;  // dead half-waves shadow the last row (no stores) so that shuffles stay full-wave
+    const int u = 4 * l32;
+    const float4 *igr = (const float4 *)(ig + (size_t)rc * 3 * H + u), *hgr = (const float4 *)(hg + (size_t)rc * 3 * H + u);
+    const float4 i_r = igr[0], i_z = igr[H / 4], i_n = igr[2 * H / 4];
+    const float4 h_r = hgr[0], h_z = hgr[H / 4], h_n = hgr[2 * H / 4];
+    const float4 hx = *(const float4 *)(h + (size_t)rc * H + u);
+    const float4 bi_r = *(const float4 *)(b_ih + u), bi_z = *(const float4 *)(b_ih + H + u), bi_n = *(const float4 *)(b_ih + 2 * H + u);
+    const float4 bh_r = *(const float4 *)(b_hh + u), bh_z = *(const float4 *)(b_hh + H + u), bh_n = *(const float4 *)(b_hh + 2 * H + u);
+    float hy[4];
+    {
+        const float ir[4] = {i_r.x, i_r.y, i_r.z, i_r.w}, iz[4] = {i_z.x, i_z.y, i_z.z, i_z.w}, in_[4] = {i_n.x, i_n.y, i_n.z, i_n.w};
+        const float hr[4] = {h_r.x, h_r.y, h_r.z, h_r.w}, hz[4] = {h_z.x, h_z.y, h_z.z, h_z.w}, hn[4] = {h_n.x, h_n.y, h_n.z, h_n.w};
+        const float b1r[4] = {bi_r.x, bi_r.y, bi_r.z, bi_r.w}, b1z[4] = {bi_z.x, bi_z.y, bi_z.z, bi_z.w}, b1n[4] = {bi_n.x, bi_n.y, bi_n.z, bi_n.w};
+        const float b2r[4] = {bh_r.x, bh_r.y, bh_r.z, bh_r.w}, b2z[4] = {bh_z.x, bh_z.y, bh_z.z, bh_z.w}, b2n[4] = {bh_n.x, bh_n.y, bh_n.z, bh_n.w};
+        const float hp[4] = {hx.x, hx.y, hx.z, hx.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float rg = sigm(ir[k] + hr[k] + b1r[k] + b2r[k]);
+            const float zg = sigm(iz[k] + hz[k] + b1z[k] + b2z[k]);
+            const float ng = tanhf(in_[k] + b1n[k] + rg * (hn[k] + b2n[k]));
+            hy[k] = ng + zg * (hp[k] - ng);
+        }
+    }
+    if (live) *(float4 *)(h + (size_t)r * H + u) = float4{hy[0], hy[1], hy[2], hy[3]};
+    int best = 0;
+    float bv = 0.0f;
+    for (int a = 0; a < A; ++a) {
+        const float4 w = *(const float4 *)(fc_w + a * H + u);
+        float v = fmaf(hy[3], w.w, fmaf(hy[2], w.z, fmaf(hy[1], w.y, hy[0] * w.x)));
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        v += fc_b[a];
+        if (q_out && live && l32 == 0) q_out[(size_t)r * A + a] = v;
+        if (a == 0 || v > bv) { bv = v; best = a; }
+    }
+    if (l32 != 0 || !live) return;
+    int act = best;
+    if (!evaluate) {
+        uint32_t w[4];
+        philox(k0, k1, (uint32_t)r, *draw_p, 0u, 0x600u, w);
+        const float u1 = (float)(w[0] >> 8) * (1.0f / 16777216.0f);
+        if (u1 < *eps_p) act = (int)__umulhi(w[1], (uint32_t)A);
+    }
+    actions[r] = act;
+    int8_t *lo = last_onehot + (size_t)r * A;
+    for (int k = 0; k < A; ++k) lo[k] = (int8_t)(k == act);
+    if (ep_u) {
+        const int e = r / n, a = r - e * n;
+        const size_t slot = ((size_t)e * T + t) * n + a;
+        ep_u[slot] = (int8_t)act;
+        if (ep_onehot) {
+            int8_t *eo = ep_onehot + slot * A;
+            for (int k = 0; k < A; ++k) eo[k] = (int8_t)(k == act);
+        }
+    }
+}
+
 constexpr int kPostBlock = 256;
 
 // One thread per chip; the two live-chip counts go through a 4-int device workspace (ws[0] = alive after, published by
@@ -133,6 +205,25 @@ int rollout_select_actions(const float *d_q, int32_t n_envs, int32_t n_agents, i
     hipLaunchKernelGGL(k_select, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_q, (int)rows, n_agents, n_actions,
                        d_epsilon, evaluate, (uint32_t)seed, (uint32_t)(seed >> 32), d_draw, d_actions, d_last_onehot, d_ep_u, d_ep_onehot,
                        episode_limit, t);
+    return finish();
+}
+
+int rollout_gru_head_select(const float *d_igates, const float *d_hgates, const float *d_b_ih, const float *d_b_hh, float *d_h,
+                            const float *d_fc_w, const float *d_fc_b, int32_t n_envs, int32_t n_agents, int32_t hidden,
+                            int32_t n_actions, const float *d_epsilon, int32_t evaluate, uint64_t seed, const uint32_t *d_draw,
+                            int32_t *d_actions, int8_t *d_last_onehot, int8_t *d_ep_u, int8_t *d_ep_onehot, int32_t episode_limit,
+                            int32_t t, float *d_q, void *stream) {
+    if (!d_igates || !d_hgates || !d_b_ih || !d_b_hh || !d_h || !d_fc_w || !d_fc_b || !d_actions || !d_last_onehot || n_envs < 0 ||
+        n_agents < 1 || hidden != 128 || n_actions < 1 || n_actions > 16 || (!evaluate && (!d_epsilon || !d_draw)) ||
+        (d_ep_u && (t < 0 || t >= episode_limit)))
+        return ROLLOUT_ERR_BAD_ARG;
+    const long rows = (long)n_envs * n_agents;
+    if (rows == 0) return ROLLOUT_OK;
+    if (rows > 0x7fffffffL) return ROLLOUT_ERR_BAD_ARG;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_gru_head_select, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, d_igates, d_hgates, d_b_ih,
+                       d_b_hh, d_h, d_fc_w, d_fc_b, (int)rows, n_agents, n_actions, d_epsilon, evaluate, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), d_draw, d_actions, d_last_onehot, d_ep_u, d_ep_onehot, episode_limit, t, d_q);
     return finish();
 }
 

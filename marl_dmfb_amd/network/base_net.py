@@ -482,6 +482,17 @@ class CRNN(nn.Module):
                 and self.input_dim[:3] == (3, 9, 9) and len(self.convs) == 2 and self.convs[0].out_channels in (24, 32)
                 and self.convs[0].weight.is_contiguous() and self.convs[1].weight.is_contiguous())
 
+    def act_ok(self, obs_i8):
+        """True when a rollout lock-step can use `act_gates` + rollout_gru_head_select (include/rollout_ops.h)."""
+        return (self._hip_conv_ok(obs_i8) and self.mlp1.in_features == 2 + self.n_actions and self.n_actions <= 16
+                and self.mlp1.out_features == 10)
+
+    def act_gates(self, obs_i8, last_action_onehot, hidden_state):
+        """The GEMM part of one rollout lock-step: x = front end (HIP), then the two GRU projections x W_ih^T and
+        h W_hh^T (no bias).  The gate math, fc1 and the epsilon-greedy pick follow in ONE kernel."""
+        x = self._front_features_hip(obs_i8, last_action_onehot)
+        return torch.matmul(x, self.rnn.weight_ih.t()), torch.matmul(hidden_state, self.rnn.weight_hh.t())
+
     def forward_obs(self, obs_i8, last_action_onehot, hidden_state):
         """obs_i8 (R, 3*fov*fov+2) int8 as written by the env kernels; last_action_onehot (R, n_actions)."""
         if self._hip_conv_ok(obs_i8) and self.mlp1.in_features == 2 + self.n_actions and self.n_actions <= 16:

@@ -100,7 +100,7 @@ def test_rollout_ops_library_exports():
     txt = open(os.path.join(ROOT, 'include', 'rollout_ops.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     names = sorted(set(re.findall(r'\b(rollout_[a-z_0-9]+)\s*\(', txt)))
-    assert names == ['rollout_last_hip_error', 'rollout_post_step', 'rollout_select_actions']
+    assert names == ['rollout_gru_head_select', 'rollout_last_hip_error', 'rollout_post_step', 'rollout_select_actions']
     for n in names:
         assert hasattr(lib, n)
     assert lib.rollout_select_actions(None, 4, 2, 5, None, 1, 0, None, None, None, None, None, 10, 0, None) == -1

@@ -100,3 +100,37 @@ def test_post_step(f64):
     assert n_alive.tolist() == [int(alive.sum()), 0, 0, 0] and int(draw) == 42
     want_eps = max(np.float32(0.9) - np.float32(1e-4) * np.float32(int(a0.sum())), np.float32(0.05))
     assert abs(float(eps) - float(want_eps)) < 1e-6
+
+
+@pytest.mark.parametrize('A,H', [(5, 128), (9, 128)])
+def test_gru_head_select_matches_grucell_and_linear(A, H):
+    """rollout_gru_head_select against nn.GRUCell + nn.Linear + argmax on the same projections (network/base_net.py:69-70,
+    agent/agent.py:45).  fp32 tolerances: h 1e-6 absolute, q 1e-5; the action must be the argmax of the kernel's own q."""
+    from marl_dmfb_amd import _lib
+    lib = _lib.rollout_ops()
+    E, n, F = 33, 4, 70
+    R = E * n
+    torch.manual_seed(A)
+    cell = torch.nn.GRUCell(F, H).cuda()
+    fc = torch.nn.Linear(H, A).cuda()
+    x = torch.randn(R, F, device='cuda')
+    h0 = torch.rand(R, H, device='cuda') * 2 - 1
+    with torch.no_grad():
+        h_ref = cell(x, h0)
+        q_ref = fc(h_ref)
+        ig = x @ cell.weight_ih.t()
+        hg = h0 @ cell.weight_hh.t()
+    h = h0.clone()
+    actions = torch.full((R,), -1, dtype=torch.int32, device='cuda')
+    last = torch.zeros((R, A), dtype=torch.int8, device='cuda')
+    q = torch.zeros((R, A), device='cuda')
+    vp = C.c_void_p
+    rc = lib.rollout_gru_head_select(vp(ig.data_ptr()), vp(hg.data_ptr()), vp(cell.bias_ih.data_ptr()), vp(cell.bias_hh.data_ptr()),
+                                     vp(h.data_ptr()), vp(fc.weight.data_ptr()), vp(fc.bias.data_ptr()), E, n, H, A, None, 1, 0, None,
+                                     vp(actions.data_ptr()), vp(last.data_ptr()), None, None, 1, 0, vp(q.data_ptr()), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(h.cpu().numpy(), h_ref.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(q.cpu().numpy(), q_ref.cpu().numpy(), rtol=0, atol=1e-5)
+    assert torch.equal(actions.long(), q.argmax(dim=1))
+    assert torch.equal(last, torch.nn.functional.one_hot(actions.long(), A).to(torch.int8))
