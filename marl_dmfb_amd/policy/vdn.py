@@ -113,28 +113,25 @@ class VDN:
         self.target_rnn.load_state_dict(self.eval_rnn.state_dict())
 
     def _allreduce_grads(self, mask_sum):
-        """ONE collective per learn step: [all gradients of the un-normalised loss, mask count]."""
+        """ONE collective per learn step: [all gradients of the un-normalised loss, mask count].  Flatten = one
+        concatenation, un-flatten = one scale + one multi-tensor copy, so a rank adds ~4 launches to the all-reduce."""
         params = [p for p in self.eval_parameters if p.grad is not None]
         n = sum(p.numel() for p in params)
-        if self._flat is None or self._flat.numel() != n + 1:
-            self._flat = torch.empty(n + 1, dtype=torch.float32, device=self.device)
-        off = 0
-        for p in params:
-            self._flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
-            off += p.numel()
-        self._flat[n] = mask_sum
-        if self._flat.is_cuda and torch.distributed.get_backend() == 'gloo':
+        flat = torch.cat([p.grad.reshape(-1) for p in params] + [mask_sum.reshape(1).to(torch.float32)])
+        if flat.is_cuda and torch.distributed.get_backend() == 'gloo':
             # rehearsal only (several ranks sharing one GPU over gloo): stage through the host
-            host = self._flat.cpu()
+            host = flat.cpu()
             torch.distributed.all_reduce(host, op=torch.distributed.ReduceOp.SUM)
-            self._flat.copy_(host)
+            flat.copy_(host)
         else:
-            torch.distributed.all_reduce(self._flat, op=torch.distributed.ReduceOp.SUM)
-        total = self._flat[n]
-        off = 0
+            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
+        total = flat[n].clone()
+        flat.div_(total)
+        views, off = [], 0
         for p in params:
-            p.grad.copy_((self._flat[off:off + p.numel()] / total).view_as(p))
+            views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        torch._foreach_copy_([p.grad for p in params], views)
         return total
 
     # ------------------------------------------------------------------ learn (policy/vdn.py:79-132)
