@@ -131,6 +131,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
         for (int tap = 0; tap < 9; ++tap) bw2[cq * 9 + tap] = chv ? w2[((size_t)ch * OD + 4 * cq + kq) * 9 + tap] : 0.0f;
     const float bias1 = chv ? b1[ch] : 0.0f, bias2 = chv ? b2[ch] : 0.0f;
     const int n_feat = OD * 25 + (mlp_w ? 10 : 0);
+    const bool wide_out = (out_stride % 2 == 0) && (((size_t)out) % 8 == 0);
 
     const long n_blocks = (rows + G::RB - 1) / G::RB;
     const int nin = 2 + n_actions;
@@ -247,10 +248,18 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
         park();  // s_in / s_vec were last read before this barrier
         // ---- stream the staged rows out: a wave per row, consecutive lanes on consecutive floats
 #ifndef CRNN_PROBE_SKIP_OUT
-        for (int rr = wave; rr < rv; rr += kBlockM / 64) {
-            float *dst = out + (row0 + rr) * out_stride;
-            const float *src = s_out + rr * G::OUT_STRIDE;
-            for (int k = lane; k < n_feat; k += 64) dst[k] = src[k];
+        if (wide_out) {  // 8-byte stores: n_feat, OUT_STRIDE and (checked once) out / out_stride are even
+            for (int rr = wave; rr < rv; rr += kBlockM / 64) {
+                float2 *dst = (float2 *)(out + (row0 + rr) * out_stride);
+                const float2 *src = (const float2 *)(s_out + rr * G::OUT_STRIDE);
+                for (int k = lane; k < n_feat / 2; k += 64) dst[k] = src[k];
+            }
+        } else {
+            for (int rr = wave; rr < rv; rr += kBlockM / 64) {
+                float *dst = out + (row0 + rr) * out_stride;
+                const float *src = s_out + rr * G::OUT_STRIDE;
+                for (int k = lane; k < n_feat; k += 64) dst[k] = src[k];
+            }
         }
 #endif
         // next iteration: s_a1 is rewritten after its first barrier, s_out after its second
