@@ -54,13 +54,17 @@ int rollout_gru_head_select(const float *d_igates, const float *d_hgates, const 
  *   d_n_alive[0] = #{e: d_alive[e]} after the update (the host polls it to stop an all-finished round early); d_n_alive
  *                 is an int32[4] workspace that must be ZERO before the first call ([1..3] are returned to zero by every call)
  *   *d_draw += 1 (the Philox draw counter of rollout_select_actions; may be NULL)
+ * and, when d_ep_o / d_ep_o_next are non-NULL (int8[E][T][obs_row_bytes], ZERO-initialised by the caller; d_obs =
+ * int8[E][obs_row_bytes], the observation after this step), the observation appends with the padding rule applied:
+ *   o_next[e][t] = obs[e] if a;   o[e][t+1] = obs[e] if a && !term[e] && t + 1 < T   (masked rows stay zero)
  * d_constraints is int32[E] (constraints_f64 == 0, DMFB) or float64[E] (== 1, MEDA). Frozen chips report
  * team_reward 0, constraints 0, success 0, term 1 from the env kernels. */
 int rollout_post_step(int32_t n_envs, int32_t episode_limit, int32_t t, uint8_t *d_alive, const uint8_t *d_term,
                       const double *d_team_reward, const void *d_constraints, int32_t constraints_f64,
                       const uint8_t *d_success, float *d_ep_r, uint8_t *d_ep_padded, uint8_t *d_ep_terminated,
                       double *d_sum_reward, double *d_sum_constraints, int64_t *d_sum_success, int64_t *d_steps,
-                      float *d_epsilon, float anneal, float min_epsilon, int32_t *d_n_alive, uint32_t *d_draw, void *stream);
+                      float *d_epsilon, float anneal, float min_epsilon, int32_t *d_n_alive, uint32_t *d_draw,
+                      const int8_t *d_obs, int32_t obs_row_bytes, int8_t *d_ep_o, int8_t *d_ep_o_next, void *stream);
 
 int rollout_last_hip_error(void);
 

@@ -169,7 +169,7 @@ def rollout_ops():
     vp, i32, u32, u64, f32 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_float
     lib.rollout_select_actions.argtypes = [vp, i32, i32, i32, vp, i32, u64, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.rollout_gru_head_select.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, u64, vp, vp, vp, vp, vp, i32, i32, vp, vp]
-    lib.rollout_post_step.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp]
+    lib.rollout_post_step.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp]
     lib.rollout_last_hip_error.argtypes = []
     lib._typed = True
     return lib

@@ -109,7 +109,7 @@ class Evaluator:
         min_eps = float(getattr(self, 'min_epsilon', 0.0))
         ep = None
         null = vp(None)
-        p_u = p_oh = p_r = p_pad = p_term = null
+        p_u = p_oh = p_r = p_pad = p_term = p_o = p_on = null
         if record:
             O = self.env.obs_len
             ep = {'o': torch.zeros((E, T, n, O), dtype=torch.int8, device=dev),
@@ -123,6 +123,8 @@ class Evaluator:
                   'terminated': torch.ones((E, T, 1), dtype=torch.bool, device=dev)}
             p_u, p_oh, p_r = vp(ep['u'].data_ptr()), vp(ep['u_onehot'].data_ptr()), vp(ep['r'].data_ptr())
             p_pad, p_term = vp(ep['padded'].data_ptr()), vp(ep['terminated'].data_ptr())
+            # o / o_next are appended by rollout_post_step with the padding rule applied (frozen chips keep zero rows)
+            p_o, p_on = vp(ep['o'].data_ptr()), vp(ep['o_next'].data_ptr())
             ep['o'][:, 0] = obs
         net = self.agents.policy.eval_rnn
         fused_tail = (self.fuse_tail and hasattr(net, 'act_ok') and net.act_ok(obs.reshape(E * n, -1)) and hidden.is_contiguous()
@@ -148,15 +150,14 @@ class Evaluator:
                 raise RuntimeError('rollout action selection failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
             # frozen chips are not stepped: the kernel reports reward 0 / constraints 0 / success 0 / terminated 1
             obs, _, _, info = self.env.step(actions, active=alive, record=True)
-            if record:  # frozen chips (alive == 0 before this step) keep zero rows: the padding rule of rollout.py:131-141
-                torch.mul(obs, alive.view(E, 1, 1), out=ep['o_next'][:, t])
             cons = info['constraints']
             rc = lib.rollout_post_step(E, T, t, vp(alive.data_ptr()), vp(info['terminated'].data_ptr()),
                                        vp(info['team_reward'].data_ptr()), vp(cons.data_ptr()), int(cons.dtype == torch.float64),
                                        vp(info['success'].data_ptr()), p_r, p_pad, p_term, vp(reward.data_ptr()),
                                        vp(constraints.data_ptr()), vp(success.data_ptr()), vp(steps.data_ptr()),
                                        vp(eps.data_ptr()), anneal, min_eps, vp(self._n_alive.data_ptr()),
-                                       vp(self._draw.data_ptr()), stream)
+                                       vp(self._draw.data_ptr()), vp(obs.data_ptr()), n * self.env.obs_len if record else 0,
+                                       p_o, p_on, stream)
             if rc != 0:
                 raise RuntimeError('rollout_post_step failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
             t_played = t + 1
@@ -165,8 +166,6 @@ class Evaluator:
         if record:  # padding rules of rollout.py:131-141 applied once: zeros, avail 0 where padded
             valid = ~ep['padded']                                   # (E, T, 1)
             v4 = valid.unsqueeze(-1)
-            if t_played > 1:  # o[t] of a chip that is still alive at t IS o_next[t-1]; zero otherwise
-                torch.mul(ep['o_next'][:, :t_played - 1], v4[:, 1:t_played], out=ep['o'][:, 1:t_played])
             for key in ('u', 'u_onehot'):
                 ep[key] *= v4
             ep['r'] *= valid

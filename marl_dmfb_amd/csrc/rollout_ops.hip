@@ -128,6 +128,21 @@ __global__ __launch_bounds__(256) void k_gru_head_select(const float *__restrict
 
 constexpr int kPostBlock = 256;
 
+// Episode observation appends of lock-step t (rollout.py:118-141 incl. the zero padding): with a = alive before the
+// step, o_next[e][t] = a ? obs[e] : 0 and o[e][t+1] = (a && !term[e]) ? obs[e] : 0 (o[t+1] of a chip that plays on IS
+// o_next[t]).  The episode tensors start zeroed, so masked rows are simply not written.  VEC = bytes per thread.
+template <typename V>
+__global__ void k_obs_append(const V *__restrict__ obs, int E, int row_v, int T, int t, const uint8_t *__restrict__ alive,
+                             const uint8_t *__restrict__ term, V *__restrict__ ep_o, V *__restrict__ ep_o_next) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)E * row_v) return;
+    const int e = (int)(idx / row_v), k = (int)(idx - (long)e * row_v);
+    if (!alive[e]) return;
+    const V v = obs[idx];
+    if (ep_o_next) ep_o_next[((size_t)e * T + t) * row_v + k] = v;
+    if (ep_o && t + 1 < T && !term[e]) ep_o[((size_t)e * T + t + 1) * row_v + k] = v;
+}
+
 // One thread per chip; the two live-chip counts go through a 4-int device workspace (ws[0] = alive after, published by
 // the last workgroup; ws[1], ws[2] = running sums; ws[3] = ticket) so that any number of workgroups can take part.
 __global__ __launch_bounds__(kPostBlock) void k_post(int E, int T, int t, uint8_t *__restrict__ alive, const uint8_t *__restrict__ term,
@@ -231,13 +246,26 @@ int rollout_post_step(int32_t n_envs, int32_t episode_limit, int32_t t, uint8_t 
                       const double *d_team_reward, const void *d_constraints, int32_t constraints_f64,
                       const uint8_t *d_success, float *d_ep_r, uint8_t *d_ep_padded, uint8_t *d_ep_terminated,
                       double *d_sum_reward, double *d_sum_constraints, int64_t *d_sum_success, int64_t *d_steps,
-                      float *d_epsilon, float anneal, float min_epsilon, int32_t *d_n_alive, uint32_t *d_draw, void *stream) {
+                      float *d_epsilon, float anneal, float min_epsilon, int32_t *d_n_alive, uint32_t *d_draw,
+                      const int8_t *d_obs, int32_t obs_row_bytes, int8_t *d_ep_o, int8_t *d_ep_o_next, void *stream) {
     if (!d_alive || !d_term || !d_team_reward || !d_constraints || !d_success || !d_sum_reward || !d_sum_constraints ||
         !d_sum_success || !d_steps || !d_n_alive || n_envs < 0 || (anneal > 0.0f && !d_epsilon) ||
-        ((d_ep_r || d_ep_padded || d_ep_terminated) && (t < 0 || t >= episode_limit)))
+        ((d_ep_r || d_ep_padded || d_ep_terminated || d_ep_o || d_ep_o_next) && (t < 0 || t >= episode_limit)) ||
+        ((d_ep_o || d_ep_o_next) && (!d_obs || obs_row_bytes < 1)))
         return ROLLOUT_ERR_BAD_ARG;
     if (n_envs == 0) return ROLLOUT_OK;
     (void)hipGetLastError();
+    if (d_ep_o || d_ep_o_next) {  // reads d_alive BEFORE k_post (same stream) updates it
+        const bool dw = obs_row_bytes % 4 == 0 && ((size_t)d_obs | (size_t)d_ep_o | (size_t)d_ep_o_next) % 4 == 0;
+        const int row_v = dw ? obs_row_bytes / 4 : obs_row_bytes;
+        const long n = (long)n_envs * row_v;
+        if (dw)
+            hipLaunchKernelGGL((k_obs_append<uint32_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)d_obs,
+                               n_envs, row_v, episode_limit, t, d_alive, d_term, (uint32_t *)d_ep_o, (uint32_t *)d_ep_o_next);
+        else
+            hipLaunchKernelGGL((k_obs_append<int8_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_obs, n_envs, row_v,
+                               episode_limit, t, d_alive, d_term, d_ep_o, d_ep_o_next);
+    }
     hipLaunchKernelGGL(k_post, dim3((unsigned)((n_envs + kPostBlock - 1) / kPostBlock)), dim3(kPostBlock), 0, (hipStream_t)stream, n_envs, episode_limit, t, d_alive, d_term, d_team_reward,
                        d_constraints, constraints_f64, d_success, d_ep_r, d_ep_padded, d_ep_terminated, d_sum_reward, d_sum_constraints,
                        d_sum_success, d_steps, d_epsilon, anneal, min_epsilon, d_n_alive, d_draw);

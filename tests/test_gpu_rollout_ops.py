@@ -82,12 +82,17 @@ def test_post_step(f64):
     eps = torch.tensor([0.9], device='cuda')
     n_alive = torch.zeros(4, dtype=torch.int32, device='cuda')
     draw = torch.tensor([41], dtype=torch.int32, device='cuda')
+    row = 4 * 245 if not f64 else 3 * 245   # dword path / byte path
+    obs = torch.randint(-3, 9, (E, row), dtype=torch.int8, device='cuda', generator=g)
+    ep_o = torch.zeros((E, T, row), dtype=torch.int8, device='cuda')
+    ep_on = torch.zeros((E, T, row), dtype=torch.int8, device='cuda')
     a0, r0, st0 = alive.clone(), s_r.clone(), steps.clone()
     vp = C.c_void_p
     rc = lib.rollout_post_step(E, T, t, vp(alive.data_ptr()), vp(term.data_ptr()), vp(tr.data_ptr()), vp(cons_in.data_ptr()), int(f64),
                                vp(succ.data_ptr()), vp(ep_r.data_ptr()), vp(ep_pad.data_ptr()), vp(ep_term.data_ptr()),
                                vp(s_r.data_ptr()), vp(s_c.data_ptr()), vp(s_s.data_ptr()), vp(steps.data_ptr()), vp(eps.data_ptr()),
-                               1e-4, 0.05, vp(n_alive.data_ptr()), vp(draw.data_ptr()), None)
+                               1e-4, 0.05, vp(n_alive.data_ptr()), vp(draw.data_ptr()), vp(obs.data_ptr()), row, vp(ep_o.data_ptr()),
+                               vp(ep_on.data_ptr()), None)
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(ep_r[:, t, 0], tr.float())
@@ -97,6 +102,10 @@ def test_post_step(f64):
     assert torch.equal(s_r, r0 + tr) and torch.equal(s_c, cons_in.double()) and torch.equal(s_s, succ.long())
     assert torch.equal(steps, st0 + a0.long())
     assert torch.equal(alive, a0 & (1 - term))
+    assert torch.equal(ep_on[:, t], obs * a0.view(E, 1).to(torch.int8))
+    assert torch.equal(ep_o[:, t + 1], obs * (a0 & (1 - term)).view(E, 1).to(torch.int8))
+    assert int(ep_on[:, :t].abs().sum()) == 0 and int(ep_on[:, t + 1:].abs().sum()) == 0
+    assert int(ep_o[:, :t + 1].abs().sum()) == 0 and int(ep_o[:, t + 2:].abs().sum()) == 0
     assert n_alive.tolist() == [int(alive.sum()), 0, 0, 0] and int(draw) == 42
     want_eps = max(np.float32(0.9) - np.float32(1e-4) * np.float32(int(a0.sum())), np.float32(0.05))
     assert abs(float(eps) - float(want_eps)) < 1e-6
