@@ -166,7 +166,8 @@ __global__ __launch_bounds__(kBlock) void k_conv9(const int8_t *__restrict__ obs
 //   P3  dW1[c1][c0][tap] += sum_pos dz1[c1][pos] * in[c0][pos + tap]          thread = (c1, c0, tap) item(s)
 template <int OD> struct GeoB {
     static constexpr int DZ2 = 28;  // 25 padded to a 16-byte multiple
-    static constexpr int ROW_FLOATS = OD * kA1Stride + OD * DZ2 + 244 + OD * kA1Stride;  // a1, dz2, in, dz1/da1 partial
+    static constexpr int DZ_ROW = OD * DZ2 + 4;  // +4 words: OD*28 is a multiple of the 32 LDS banks, and P2's lanes span rows
+    static constexpr int ROW_FLOATS = OD * kA1Stride + OD * DZ2 + 4 + 244 + OD * kA1Stride;  // a1, dz2 (+4 pad), in, dz1/da1 partial
     static constexpr int FIXED_FLOATS = OD * OD * 9;
     static constexpr int RBB = ((kLdsBudget / 4 - FIXED_FLOATS) / ROW_FLOATS) < (kBlock / (2 * OD)) ? ((kLdsBudget / 4 - FIXED_FLOATS) / ROW_FLOATS)
                                                                                                    : (kBlock / (2 * OD));
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     float *s_w2 = lds;                                  // [c2][tap][c1]
     float *s_a1 = s_w2 + OD * OD * 9;                   // [RBB][OD][52]
     float *s_dz2 = s_a1 + G::RBB * OD * kA1Stride;      // [RBB][OD][28]
-    float *s_in = s_dz2 + G::RBB * OD * G::DZ2;         // [RBB][244]
+    float *s_in = s_dz2 + G::RBB * G::DZ_ROW;            // [RBB][244]
     float *s_dz1 = s_in + G::RBB * 244;                 // [RBB][OD][52]
     const int tid = threadIdx.x;
     for (int i = tid; i < OD * OD * 9; i += kBlock) {   // global (c2, c1, tap) -> LDS (c2, tap, c1)
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
 #pragma unroll
             for (int u = 0; u < NPD; ++u) {
                 const int i = t_ + u * kBlock, rc = i / 25, k = i - rc * 25;
-                if (i < G::RBB * OD * 25) s_dz2[rc * G::DZ2 + k] = pfd[u];
+                if (i < G::RBB * OD * 25) s_dz2[(rc / OD) * G::DZ_ROW + (rc % OD) * G::DZ2 + k] = pfd[u];
             }
 #pragma unroll
             for (int u = 0; u < NPI; ++u) {
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
             for (int i = tid; i < rv * OD * 25; i += kBlock) {
                 const int rr = i / (OD * 25), rem = i - rr * OD * 25, c = rem / 25, k = rem - c * 25;
                 const float act = a2[(row0 + rr) * a2_stride + rem];
-                s_dz2[(rr * OD + c) * G::DZ2 + k] = act > 0.0f ? g[(row0 + rr) * g_stride + rem] : 0.0f;
+                s_dz2[rr * G::DZ_ROW + c * G::DZ2 + k] = act > 0.0f ? g[(row0 + rr) * g_stride + rem] : 0.0f;
             }
             for (int i = tid; i < rv * 243; i += kBlock) {
                 const int rr = i / 243, pp = i - rr * 243;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         auto pair_rows = [&](int c2, int c1, int r_begin, int r_step, float (&acc)[9], float *sum_dz) {
             for (int rr = r_begin; rr < rv; rr += r_step) {
                 float dz[G::DZ2], a[kA1Stride];
-                const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + (rr * OD + c2) * G::DZ2, 16);
+                const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + rr * G::DZ_ROW + c2 * G::DZ2, 16);
                 const float4 *pa = (const float4 *)__builtin_assume_aligned(s_a1 + (rr * OD + c1) * kA1Stride, 16);
 #pragma unroll
                 for (int j = 0; j < G::DZ2 / 4; ++j) { const float4 t = pd[j]; dz[4 * j] = t.x; dz[4 * j + 1] = t.y; dz[4 * j + 2] = t.z; dz[4 * j + 3] = t.w; }
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
             const int cbeg = half * (OD / 2), cend = cbeg + OD / 2;
             for (int c2 = cbeg; c2 < cend; ++c2) {
                 float dz[G::DZ2], w[9];
-                const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + (r2 * OD + c2) * G::DZ2, 16);
+                const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + r2 * G::DZ_ROW + c2 * G::DZ2, 16);
 #pragma unroll
                 for (int j = 0; j < G::DZ2 / 4; ++j) { const float4 t = pd[j]; dz[4 * j] = t.x; dz[4 * j + 1] = t.y; dz[4 * j + 2] = t.z; dz[4 * j + 3] = t.w; }
 #pragma unroll
