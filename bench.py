@@ -1,7 +1,9 @@
 """bench.py -- env-steps/sec of the vectorised DMFB + VDN training loop on N MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
-torch.distributed.run with one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  Under torch.distributed.run
+(WORLD_SIZE set) every process is one rank on one GPU (RCCL).  Started plainly with `--gpus N > 1`
+the process launches N such ranks itself (child processes, before it touches the GPU) and relays
+rank 0's line.  Rank 0 prints ONE JSON line.
 
 What one "step" is: one ROUND of the training loop of the reference's Trainer.run
 (train.py:59-78) over the whole batch of chips = every chip plays one episode in lock-step
@@ -12,10 +14,17 @@ learns of `batch_size` episodes run (forward, backward, gradient all-reduce when
 
 Workload (BASELINE.json configs[1]): DMFB 10x10, 4 droplets, fov 9, 4096 chips per GPU, synthetic
 tasks from the Philox generator, randomly initialised CRNN (hyper_hidden_dim 24, fp32).
+
+`roofline` describes the FOV-gather kernel `dmfbk::k_observe<n>` (the kernel BASELINE.json's
+north_star grades) at `--roofline_envs` chips per launch, timed live with HIP events on the launch
+stream; nothing is subtracted from the event figures.  The same kernel inside the 4096-chip training
+loop is launch-latency bound and is reported under `tiers.in_loop_step_kernel`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,7 +45,12 @@ def algo_bytes_per_env_step(n, fov, degrade=False, ext_uniforms=False):
     return writes + reads + state
 
 
-def parse():
+def fov_kernel_bytes_per_env(n, fov):
+    """the FOV-gather kernel alone, n*(3 fov^2 + 2) written + 5n + 8 read per chip."""
+    return n * (3 * fov * fov + 2) + 5 * n + 8
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
@@ -49,16 +63,58 @@ def parse():
     ap.add_argument('--batch_size', type=int, default=512, help='episodes per learn')
     ap.add_argument('--train_time', type=int, default=4, help='learns per round')
     ap.add_argument('--buffer_size', type=int, default=16384, help='episodes kept in the HBM replay buffer')
-    ap.add_argument('--graph', action='store_true', help='replay the rollout as a captured HIP graph (the in-loop kernel '
-                    'timing of the roofline object is then taken from an eager pass after the timed region)')
+    ap.add_argument('--graph', action='store_true', help='replay the rollout as a captured HIP graph')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_tiers', action='store_true')
-    ap.add_argument('--roofline_envs', type=int, default=262144, help='batch for the large-batch roofline figure')
-    return ap.parse_args()
+    ap.add_argument('--cpu_seconds', type=float, default=20.0, help='wall seconds of the cpu_baseline sample')
+    ap.add_argument('--roofline_envs', type=int, default=262144, help='chips per launch of the roofline kernel')
+    ap.add_argument('--launch_check', action='store_true',
+                    help='rendezvous + collectives only (no GPU work): checks the --gpus N launch plumbing')
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------
+# --gpus N without a launcher: start the N ranks ourselves, BEFORE this process touches the GPU
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a, argv):
+    """Child processes (one per GPU) under torch.distributed.run; relay rank 0's JSON line.  The parent makes
+    no GPU call, so nothing that initialised the GPU is ever re-executed."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        ln = ln.strip()
+        if ln.startswith('{') and '"n_gpus"' in ln:
+            line = ln
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write(proc.stdout[-4000:] + '\n' + proc.stderr[-8000:] + '\n')
+        sys.stderr.write('bench.py: the %d-rank launch failed (rc %d)\n' % (a.gpus, proc.returncode))
+        return proc.returncode or 1
+    got = json.loads(line).get('n_gpus')
+    if got != a.gpus:
+        sys.stderr.write('bench.py: asked for %d ranks, %r joined\n' % (a.gpus, got))
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# tiers measured on the GPU
+# ------------------------------------------------------------------------------------------------
 def env_only_tier(cfg, E, iters, device, fov_kernel=False):
-    """Env-only tier: fused transition kernel with auto-reset, uniform random actions."""
+    """Env-only tier: transition + observation with auto-reset, uniform random actions.  With
+    fov_kernel=True also the FOV-gather kernel alone (k_observe), `iters` launches back to back between two
+    HIP events on the launch stream (the average therefore includes the ~1.5 us kernel boundary)."""
     from marl_dmfb_amd.env.dmfb import VecDMFB
     env = VecDMFB(n_envs=E, seed=1, device=device, **cfg)
     env.reset()
@@ -75,11 +131,12 @@ def env_only_tier(cfg, E, iters, device, fov_kernel=False):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     b = algo_bytes_per_env_step(cfg['n_agents'], cfg['fov'])
-    out = {'n_envs': E, 'us_per_launch': round(us, 2), 'env_steps_per_s': round(E / us * 1e6),
-           'algo_GBps': round(E * b / us / 1e3, 1), 'frac': round(E * b / us / 1e3 / HBM_PEAK_GBPS, 4)}
+    out = {'n_envs': E, 'us_per_lockstep': round(us, 2), 'env_steps_per_s': round(E / us * 1e6),
+           'algo_bytes_per_env_step': b, 'algo_GBps': round(E * b / us / 1e3, 1),
+           'frac': round(E * b / us / 1e3 / HBM_PEAK_GBPS, 4)}
     if fov_kernel:
-        # the FOV-gather kernel alone (k_observe): n*(3 fov^2 + 2) bytes written + 4n+... read per chip
-        env.observe()
+        for _ in range(10):
+            env.observe()
         torch.cuda.synchronize()
         e0.record()
         for i in range(iters):
@@ -87,109 +144,227 @@ def env_only_tier(cfg, E, iters, device, fov_kernel=False):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
-        n, fov = cfg['n_agents'], cfg['fov']
-        fb = n * (3 * fov * fov + 2) + 5 * n + 8  # FOV-gather kernel alone
-        out['fov_kernel'] = {'kernel': 'dmfbk::k_observe<%d>' % n, 'us_per_launch': round(us, 2), 'algo_bytes_per_env': fb,
+        fb = fov_kernel_bytes_per_env(cfg['n_agents'], cfg['fov'])
+        out['fov_kernel'] = {'kernel': 'dmfbk::k_observe<%d>' % cfg['n_agents'], 'launches_timed': iters,
+                             'us_per_launch': round(us, 2), 'algo_bytes_per_env': fb,
                              'algo_GBps': round(E * fb / us / 1e3, 1), 'frac': round(E * fb / us / 1e3 / HBM_PEAK_GBPS, 4)}
     env.close()
     return out
 
 
-def cpu_baseline(cfg, args_ns, seconds=20.0):
-    """The same loop on the host CPU: the C oracle env (kind "port", 1 thread) driven by the same
-    host-side Agents/VDN code on torch CPU.  Bounded sample; rank 0, N = 1 only."""
+def loop_breakdown(trainer, rounds):
+    """env+policy tier (rollouts only, no learn) and the per-phase times of a round, each phase bracketed by a
+    device synchronisation.  Runs after the timed region, on the same trainer."""
+    a = trainer.args
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    played = 0
+    for _ in range(rounds):
+        _, _, _, _, ep = trainer.rolloutWorker.generate_episode()
+        played += int((~ep['padded']).sum().item())
+    torch.cuda.synchronize()
+    t_roll = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        trainer.buffer.store_episode(ep)
+    torch.cuda.synchronize()
+    t_store = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        for _ in range(a.train_time):
+            mb = trainer.buffer.sample(min(trainer.buffer.current_size, a.batch_size))
+            trainer.agents.train(mb, trainer.trained_times)
+            trainer.trained_times += 1
+    torch.cuda.synchronize()
+    t_learn = time.perf_counter() - t0
+    return {'env_policy': {'what': 'rollouts only: Q-net forward + epsilon-greedy + env transition, no learn',
+                           'rounds': rounds, 'env_steps_per_s': round(played / t_roll, 1),
+                           'rollout_ms': round(t_roll / rounds * 1e3, 3)},
+            'store_ms': round(t_store / rounds * 1e3, 3),
+            'learn_ms': round(t_learn / rounds * 1e3, 3),
+            'learn_ms_what': '%d learns x %d episodes (sample + forward + backward + clip + Adam)' % (a.train_time, a.batch_size)}
+
+
+def in_loop_step_kernel(trainer, env, n, fov):
+    """The env transition launch as it runs inside the 4096-chip loop: one extra eager episode (outside the timed
+    region) with a HIP event pair around every launch.  Raw event-pair figures: a pair around nothing already
+    reads a few microseconds, so this over-states the kernel's own duration (rocprofv3 has that, profiles/)."""
+    trainer.rolloutWorker.use_graph = False
+    env.timing = []
+    trainer.rolloutWorker.generate_episode()
+    torch.cuda.synchronize()
+    us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in env.timing]
+    env.timing = None
+    pairs = []
+    for _ in range(200):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    ev = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in pairs)
+    raw = sum(us) / max(1, len(us))
+    b = algo_bytes_per_env_step(n, fov)
+    return {'kernel': 'dmfbk::k_step<%d,false>' % n, 'n_envs': env.n_envs, 'launches_timed': len(us),
+            'event_pair_raw_us': round(raw, 2), 'empty_event_pair_us': round(ev[len(ev) // 2], 2),
+            'algo_bytes_per_env_step': b, 'algo_GBps_raw': round(env.n_envs * b / raw / 1e3, 1),
+            'frac_raw': round(env.n_envs * b / raw / 1e3 / HBM_PEAK_GBPS, 4),
+            'note': 'launch-latency bound at this batch (SURVEY 8(d) caveat); nothing subtracted'}
+
+
+# ------------------------------------------------------------------------------------------------
+# cpu_baseline: the reference's loop shape on the host cores (one single-chip process per core)
+# ------------------------------------------------------------------------------------------------
+def _cpu_worker(job):
+    """One host core: a single chip (C oracle behind the reference-shaped reset/step protocol), the reference's
+    rollout (n Q-net forwards of batch size 1 per step through Agents.choose_action, common/rollout.py:19-39) and
+    VDN.learn on torch CPU with ONE thread.  Returns counts and times of three phases."""
     import numpy as np
+    torch.set_num_threads(1)
     from oracle.dmfb_oracle import DmfbOracle  # cpu_baseline leg: allowed user of oracle/
     from marl_dmfb_amd.agent.agent import Agents
     from marl_dmfb_amd.common.arguments import make_args
-    # the box exposes every host core but one GPU's share is 16 (more threads only add contention)
-    cores = max(1, min(16, os.cpu_count() or 1))
-    torch.set_num_threads(cores)
+    cfg, seconds, seed, collect_per_learn, learn_batch = job
     n, fov = cfg['n_agents'], cfg['fov']
-    E = 128
     T = 2 * (cfg['width'] + cfg['length'])
+    O = 3 * fov * fov + 2
     a = make_args(drop_num=n, width=cfg['width'], length=cfg['length'], fov=fov, cuda=False, device='cpu',
-                  n_actions=5, n_agents=n, obs_shape=(3, fov, fov, 2, 3 * fov * fov + 2), episode_limit=T)
+                  n_actions=5, n_agents=n, obs_shape=(3, fov, fov, 2, O), episode_limit=T)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
     agents = Agents(a)
-    ora = DmfbOracle(n_envs=E, seed=1, **cfg)
-    rng = np.random.default_rng(0)
-    # env-only: reset + step + observe, random actions, single thread
+    ora = DmfbOracle(n_envs=1, seed=seed, **cfg)
+    rng = np.random.default_rng(seed)
+    # phase 1: env only -- reset + step + observe, uniform random actions
     t0 = time.perf_counter()
     env_steps = 0
     ora.reset()
-    while time.perf_counter() - t0 < seconds * 0.25:
-        r, d, c, s = ora.step(rng.integers(0, 5, (E, n)).astype(np.int32))
-        term = d.all(axis=1)
-        if term.any():
-            ora.reset(mask=term.astype(np.uint8))
+    while time.perf_counter() - t0 < seconds * 0.15:
+        r, d, c, s = ora.step(rng.integers(0, 5, (1, n)).astype(np.int32))
+        if d.all():
+            ora.reset()
         ora.observe()
-        env_steps += E
-    env_only = env_steps / (time.perf_counter() - t0)
-    # full loop: one episode per chip with the CRNN on CPU, then learns at the GPU run's cadence
+        env_steps += 1
+    t_env = time.perf_counter() - t0
+    # phase 2+3: the full loop -- episodes through choose_action (B = 1 per agent), learns at the GPU run's
+    # learn/collect ratio
+    avail = np.ones(5)
+    episodes = []
     t0 = time.perf_counter()
-    played = 0
-    rounds = 0
-    while time.perf_counter() - t0 < seconds * 0.75 or rounds == 0:
+    played = learn_s = 0.0
+    learns = 0
+    eps = 0.5
+    while time.perf_counter() - t0 < seconds * 0.85:
         ora.reset()
-        obs = torch.from_numpy(ora.observe())
-        hidden = torch.zeros((E * n, a.rnn_hidden_dim))
-        last = torch.zeros((E, n, 5), dtype=torch.int8)
-        alive = np.ones(E, bool)
-        ep = {'o': torch.zeros((E, T, n, obs.shape[-1]), dtype=torch.int8), 'o_next': torch.zeros((E, T, n, obs.shape[-1]), dtype=torch.int8),
-              'u': torch.zeros((E, T, n, 1), dtype=torch.int8), 'r': torch.zeros((E, T, 1)),
-              'avail_u': torch.zeros((E, T, n, 5), dtype=torch.int8), 'avail_u_next': torch.zeros((E, T, n, 5), dtype=torch.int8),
-              'u_onehot': torch.zeros((E, T, n, 5), dtype=torch.int8), 'padded': torch.ones((E, T, 1), dtype=torch.bool),
-              'terminated': torch.ones((E, T, 1), dtype=torch.bool)}
+        obs = ora.observe()[0]
+        agents.policy.init_hidden(1)
+        last = np.zeros((n, 5))
+        ep = {'o': np.zeros((T, n, O), np.int8), 'o_next': np.zeros((T, n, O), np.int8), 'u': np.zeros((T, n, 1), np.int8),
+              'r': np.zeros((T, 1), np.float32), 'avail_u': np.zeros((T, n, 5), np.int8), 'avail_u_next': np.zeros((T, n, 5), np.int8),
+              'u_onehot': np.zeros((T, n, 5), np.int8), 'padded': np.ones((T, 1), bool), 'terminated': np.ones((T, 1), bool)}
         for t in range(T):
-            acts, hidden = agents.choose_actions(obs, last, hidden, 0.5)
-            onehot = torch.nn.functional.one_hot(acts, 5).to(torch.int8)
-            # the single-chip reference stops stepping a finished chip; emulate with a per-env mask
-            idx = np.nonzero(alive)[0]
-            ep['o'][idx, t] = obs[idx]
-            r, d, c, s = ora.step(acts.numpy().astype(np.int32))
-            obs = torch.from_numpy(ora.observe())
-            term = d.all(axis=1)
-            ep['o_next'][idx, t] = obs[idx]
-            ep['u'][idx, t] = acts[idx].unsqueeze(-1).to(torch.int8)
-            ep['u_onehot'][idx, t] = onehot[idx]
-            ep['avail_u'][idx, t] = 1
-            ep['avail_u_next'][idx, t] = 1
-            ep['r'][idx, t, 0] = torch.from_numpy((r.sum(axis=1) / n)[idx]).float()
-            ep['padded'][idx, t] = False
-            ep['terminated'][idx, t, 0] = torch.from_numpy(term[idx])
-            played += int(alive.sum())
-            last = onehot
-            alive = alive & ~term
-            if not alive.any():
+            acts = [int(agents.choose_action(obs[i], last[i], i, avail, eps)) for i in range(n)]
+            r, d, c, s = ora.step(np.asarray(acts, np.int32)[None])
+            nxt = ora.observe()[0]
+            onehot = np.eye(5)[acts]
+            ep['o'][t], ep['o_next'][t], ep['u'][t, :, 0], ep['u_onehot'][t] = obs, nxt, acts, onehot
+            ep['r'][t, 0] = r.sum() / n
+            ep['avail_u'][t] = 1; ep['avail_u_next'][t] = 1
+            ep['padded'][t] = False; ep['terminated'][t] = bool(d.all())
+            obs, last = nxt, onehot
+            played += 1
+            if d.all():
                 break
-        learns = max(1, round(args_ns.train_time * args_ns.batch_size * E / (args_ns.n_envs * 64)))
-        for k in range(learns):
-            sel = torch.randint(0, E, (64,))
-            agents.train({key: v[sel] for key, v in ep.items()}, k)
-        rounds += 1
-    full = played / (time.perf_counter() - t0)
-    return {'value': round(full, 1), 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
-            'env_only_value_1core': round(env_only, 1),
-            'sample': '%d rounds of %d chips x <=%d lock-steps (CRNN on torch CPU, %d threads) + learns of 64 '
-                      'episodes at the GPU run\'s learn/collect ratio; env = C oracle, 1 thread' % (rounds, E, T, cores)}
+        episodes.append(ep)
+        if len(episodes) % collect_per_learn == 0:
+            tl = time.perf_counter()
+            sel = rng.integers(0, len(episodes), learn_batch)
+            batch = {k: torch.from_numpy(np.stack([episodes[j][k] for j in sel])) for k in ep}
+            agents.train(batch, learns)
+            learns += 1
+            learn_s += time.perf_counter() - tl
+            episodes = episodes[-4 * collect_per_learn:]
+    t_full = time.perf_counter() - t0
+    return {'env_steps': env_steps, 't_env': t_env, 'played': played, 't_full': t_full, 'learns': learns, 'learn_s': learn_s}
 
 
-def main():
-    a = parse()
+def _cpu_model():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.lower().startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(cfg, a):
+    """The reference's own loop shape timed on the host: one single-threaded process per core, each a single chip +
+    B=1 Q-net forwards + VDN.learn.  Env = the C oracle (kind "port"; the reference's Python env cannot travel to the
+    GPU box), so the env share is a generous stand-in: the reference's Python DMFBenv steps ~2.6e3/s per core
+    (BASELINE.md).  Five processes, not one per host core: torch's autograd engine opens the GPU device nodes in
+    every process that calls backward() -- also on CPU tensors, whatever *_VISIBLE_DEVICES says (tools/probe/
+    gpu_open_probe.py) -- and the GPU box admits six processes with the GPU open (this one + five)."""
+    import multiprocessing as mp
+    cores = max(1, min(5, os.cpu_count() or 1))
+    sampled_per_collected = a.train_time * a.batch_size / float(a.n_envs)   # the GPU run's learn/collect ratio
+    learn_batch = 32
+    collect_per_learn = max(1, int(round(learn_batch / max(sampled_per_collected, 1e-9))))
+    ctx = mp.get_context('spawn')  # never fork a process that holds a GPU context
+    jobs = [(cfg, float(a.cpu_seconds), 100 + k, collect_per_learn, learn_batch) for k in range(cores)]
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    env_only = sum(r['env_steps'] / r['t_env'] for r in res)
+    full = sum(r['played'] / r['t_full'] for r in res)
+    return {'value': round(full, 1), 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port', 'cpu_model': _cpu_model(),
+            'per_core': round(full / cores, 1), 'env_only_value': round(env_only, 1), 'env_only_per_core': round(env_only / cores, 1),
+            'learns': int(sum(r['learns'] for r in res)),
+            'sample': '%d processes x %.0f s, one chip each: 15%% env-only (C oracle reset/step/observe, random actions), 85%% the '
+                      'reference loop shape (per step %d Q-net forwards of batch 1 via Agents.choose_action, torch CPU 1 thread; '
+                      'one VDN.learn of %d episodes per %d collected = the GPU run\'s %.2f sampled per collected episode)'
+                      % (cores, a.cpu_seconds, cfg['n_agents'], learn_batch, collect_per_learn, sampled_per_collected)}
+
+
+# ------------------------------------------------------------------------------------------------
+def launch_check(a, world, rank, backend):
+    """Rendezvous, one SUM and one MAX all-reduce, one line from rank 0.  No GPU work: this only proves that
+    `--gpus N` produces N cooperating ranks."""
+    import torch.distributed as dist
+    dist.init_process_group('gloo' if backend != 'nccl' or not torch.cuda.is_available() else backend)
+    t = torch.tensor([1.0, float(rank)], dtype=torch.float64)
+    dist.all_reduce(t[0:1], op=dist.ReduceOp.SUM)
+    dist.all_reduce(t[1:2], op=dist.ReduceOp.MAX)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({'launch_check': True, 'n_gpus': int(t[0].item()), 'max_rank': int(t[1].item()),
+                          'asked': a.gpus}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse(argv)
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(a, argv)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (a.gpus, world))
+        return 2
+    # BENCH_DIST_BACKEND=gloo rehearses the multi-rank control flow with all ranks on one GPU
+    backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+    if a.launch_check:
+        return launch_check(a, world, rank, backend)
     # BENCH_FORCE_DIST=1 runs the collective path (RCCL init, broadcast, all-reduce) even with one rank
     force_dist = bool(os.environ.get('BENCH_FORCE_DIST'))
     dist = world > 1 or force_dist
-    # BENCH_DIST_BACKEND=gloo rehearses the multi-rank control flow with all ranks on one GPU
-    backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if dist:
         if force_dist and 'MASTER_ADDR' not in os.environ:
-            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1')
         if backend == 'nccl':
             torch.distributed.init_process_group('nccl', device_id=device)
         else:
@@ -210,7 +385,6 @@ def main():
 
     for _ in range(a.warmup):
         trainer.collect_and_learn()
-    env.timing = []
     torch.cuda.synchronize()
     if dist:
         torch.distributed.barrier()
@@ -222,78 +396,75 @@ def main():
     if dist:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    if not env.timing:  # graph replays do not re-record the events: time one eager episode of the same loop
-        trainer.rolloutWorker.use_graph = False
-        trainer.rolloutWorker.generate_episode()
-        torch.cuda.synchronize()
-    kern_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in env.timing]
-    env.timing = None
-    # an event pair with nothing between it still measures ~2-3 us of marker latency: calibrate and subtract,
-    # so that the figure is the kernel's own duration (what rocprofv3 --kernel-trace reports)
-    pairs = []
-    for _ in range(200):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); e1.record()
-        pairs.append((e0, e1))
-    torch.cuda.synchronize()
-    ev = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in pairs)
-    event_overhead_us = ev[len(ev) // 2]
+
     tot = torch.tensor([float(played), dt], device=device, dtype=torch.float64)
     if dist:
         p = tot[0:1].clone() if backend == 'nccl' else tot[0:1].cpu()
         torch.distributed.all_reduce(p, op=torch.distributed.ReduceOp.SUM)
         m = tot[1:2].clone() if backend == 'nccl' else tot[1:2].cpu()
         torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)
-        played_all, dt_max = float(p.item()), float(m.item())
+        c = torch.ones(1, dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+        torch.distributed.all_reduce(c, op=torch.distributed.ReduceOp.SUM)
+        played_all, dt_max, joined = float(p.item()), float(m.item()), int(c.item())
     else:
-        played_all, dt_max = float(played), dt
+        played_all, dt_max, joined = float(played), dt, 1
 
     if rank != 0:
         if dist:
             torch.distributed.destroy_process_group()
-        return
+        return 0
 
-    b = algo_bytes_per_env_step(a.drop_num, a.fov)
-    raw_us = sum(kern_us) / max(1, len(kern_us))
-    avg_us = max(raw_us - event_overhead_us, 0.1)
-    achieved = a.n_envs * b / avg_us / 1e3  # GB/s
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get('k_step_%dx%d_%dd_E%d' % (a.width, a.length, a.drop_num, a.n_envs))
-        except Exception:
-            traffic = None
+    n, fov = a.drop_num, a.fov
     out = {
-        'metric': 'env-steps/sec (whole node), %dx%d DMFB %d-droplet fov%d' % (a.width, a.length, a.drop_num, a.fov),
-        'value': round(played_all / dt_max, 1), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': a.steps,
+        'metric': 'env-steps/sec (whole node), %dx%d DMFB %d-droplet fov%d' % (a.width, a.length, n, fov),
+        'value': round(played_all / dt_max, 1), 'unit': 'env-steps/s', 'n_gpus': joined, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': round(dt_max / a.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8 env state/obs + f64 rewards; fp32 Q-net',
         'data': 'synthetic (Philox task generator, random-init CRNN)',
         'config': {'workload': 'DMFB %dx%d, drop_num=%d, fov=%d, %d parallel envs per GPU%s' % (
-            a.width, a.length, a.drop_num, a.fov, a.n_envs,
-            ' (BASELINE configs[1])' if (a.width, a.length, a.drop_num, a.fov, a.n_envs) == (10, 10, 4, 9, 4096) else ''),
+            a.width, a.length, n, fov, a.n_envs,
+            ' (BASELINE configs[1])' if (a.width, a.length, n, fov, a.n_envs) == (10, 10, 4, 9, 4096) else ''),
             'round': 'one episode per chip (<=%d lock-steps) + %d learns x %d episodes' % (
                 env.max_step, a.train_time, a.batch_size),
             'parallelism': 'dp%d: chips sharded per rank, one flat RCCL all-reduce per learn' % world,
             'env_steps_per_round': round(played_all / a.steps, 1)},
-        'roofline': {'bound': 'hbm', 'kernel': 'dmfbk::k_step<%d,false>' % a.drop_num, 'achieved': round(achieved, 1),
-                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 4),
-                     'traffic': traffic, 'launches_timed': len(kern_us), 'avg_launch_us': round(avg_us, 2),
-                     'event_pair_raw_us': round(raw_us, 2), 'event_overhead_us': round(event_overhead_us, 2),
-                     'algo_bytes_per_env_step': b, 'envs_per_launch': a.n_envs},
     }
-    if not a.no_tiers and world == 1:
-        trainer = None
-        torch.cuda.empty_cache()
-        out['tiers'] = {'env_only_4096': env_only_tier(cfg, a.n_envs, 300, device),
-                        'env_only_large_batch': env_only_tier(cfg, a.roofline_envs, 100, device, fov_kernel=True)}
+    tiers = {}
+    if world == 1 and not a.no_tiers:
+        tiers.update(loop_breakdown(trainer, max(2, min(a.steps, 6))))
+        tiers['env_policy_learn'] = {'env_steps_per_s': out['value'], 'what': out['config']['round']}
+        tiers['in_loop_step_kernel'] = in_loop_step_kernel(trainer, env, n, fov)
+    trainer = None
+    env.close()
+    torch.cuda.empty_cache()
+    if True:  # every N: rank 0 times the roofline kernel on its own GPU after the timed region
+        # the roofline kernel: FOV gather at a batch where the launch runs >= 50 us (SURVEY 8(d) launch-latency caveat)
+        big = env_only_tier(cfg, a.roofline_envs, 100, device, fov_kernel=True)
+        fk = big['fov_kernel']
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get('k_observe_%dx%d_%dd_E%d' % (a.width, a.length, n, a.roofline_envs))
+            except Exception:
+                traffic = None
+        out['roofline'] = {'bound': 'hbm', 'kernel': fk['kernel'], 'achieved': fk['algo_GBps'], 'peak': HBM_PEAK_GBPS,
+                           'unit': 'GB/s', 'frac': fk['frac'], 'traffic': traffic, 'envs_per_launch': a.roofline_envs,
+                           'algo_bytes_per_env': fk['algo_bytes_per_env'], 'avg_launch_us': fk['us_per_launch'],
+                           'launches_timed': fk['launches_timed'],
+                           'timing': 'HIP events on the launch stream around %d back-to-back launches, nothing subtracted' % fk['launches_timed']}
+        if not a.no_tiers and world == 1:
+            tiers['env_only_large_batch'] = big
+            tiers['env_only_%d' % a.n_envs] = env_only_tier(cfg, a.n_envs, 300, device)
+    if tiers:
+        out['tiers'] = tiers
     if not a.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(cfg, a)
     print(json.dumps(out), flush=True)
     if dist:
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

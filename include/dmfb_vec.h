@@ -137,6 +137,12 @@ int dmfb_vec_get_state(const dmfb_vec *h, int32_t *d_pos, int32_t *d_dist, int32
 int dmfb_vec_get_map(const dmfb_vec *h, int which, double *d_buf, void *stream);
 int dmfb_vec_set_map(dmfb_vec *h, int which, const double *d_buf, void *stream);
 
+/* How the handle maps chips to workgroups (profiling aid; no reference counterpart): out[0] = chips per 256-thread
+ * workgroup of the fused step+observe launch, out[1] = chips per workgroup of the observation kernel, out[2] = batch size
+ * from which dmfb_vec_step issues a step-only launch followed by the observation kernel, out[3] = chips per workgroup of
+ * that step-only launch. */
+int dmfb_vec_launch_shape(const dmfb_vec *h, int32_t out[4]);
+
 /* Direction-vector zoom table (dmfb.py:444-453) the handle was built with: int8[2][511], host memory. */
 int dmfb_vec_zoom_lut(const dmfb_vec *h, int8_t *host_out);
 

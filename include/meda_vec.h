@@ -99,6 +99,10 @@ int meda_vec_get_state(const meda_vec *h, int32_t *d_pos, uint8_t *d_status, int
 int meda_vec_get_map(const meda_vec *h, int which, double *d_buf, void *stream); /* float64[E][width][length] */
 int meda_vec_set_map(meda_vec *h, int which, const double *d_buf, void *stream);
 
+/* How the handle maps chips to workgroups (profiling aid; no reference counterpart): out[0] = chips per workgroup of
+ * the transition kernel, out[1] = chips per workgroup of the observation kernel. */
+int meda_vec_launch_shape(const meda_vec *h, int32_t out[2]);
+
 const char *meda_vec_strerror(int code);
 int meda_vec_last_hip_error(void);
 

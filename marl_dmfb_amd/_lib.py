@@ -49,7 +49,7 @@ DMFB_VEC_SYMBOLS = [
     'dmfb_vec_check_config', 'dmfb_vec_create', 'dmfb_vec_destroy', 'dmfb_vec_state_bytes', 'dmfb_vec_obs_len',
     'dmfb_vec_max_step', 'dmfb_vec_n_envs', 'dmfb_vec_n_agents', 'dmfb_vec_reset', 'dmfb_vec_restart',
     'dmfb_vec_set_task', 'dmfb_vec_get_task', 'dmfb_vec_set_blocks', 'dmfb_vec_get_blocks', 'dmfb_vec_step', 'dmfb_vec_observe', 'dmfb_vec_get_state',
-    'dmfb_vec_get_map', 'dmfb_vec_set_map', 'dmfb_vec_zoom_lut', 'dmfb_vec_strerror', 'dmfb_vec_last_hip_error',
+    'dmfb_vec_get_map', 'dmfb_vec_set_map', 'dmfb_vec_launch_shape', 'dmfb_vec_zoom_lut', 'dmfb_vec_strerror', 'dmfb_vec_last_hip_error',
 ]
 
 
@@ -78,6 +78,7 @@ def dmfb_vec():
     lib.dmfb_vec_get_map.argtypes = [vp, i32, vp, vp]
     lib.dmfb_vec_set_map.argtypes = [vp, i32, vp, vp]
     lib.dmfb_vec_zoom_lut.argtypes = [vp, vp]
+    lib.dmfb_vec_launch_shape.argtypes = [vp, C.POINTER(C.c_int32 * 4)]
     lib.dmfb_vec_strerror.argtypes = [i32]
     lib.dmfb_vec_strerror.restype = C.c_char_p
     lib.dmfb_vec_last_hip_error.argtypes = []
@@ -102,7 +103,7 @@ MEDA_VEC_SYMBOLS = [
     'meda_vec_check_config', 'meda_vec_create', 'meda_vec_destroy', 'meda_vec_state_bytes', 'meda_vec_obs_len',
     'meda_vec_max_step', 'meda_vec_n_envs', 'meda_vec_n_agents', 'meda_vec_reset', 'meda_vec_restart',
     'meda_vec_set_task', 'meda_vec_get_task', 'meda_vec_step', 'meda_vec_observe', 'meda_vec_get_state',
-    'meda_vec_get_map', 'meda_vec_set_map', 'meda_vec_strerror', 'meda_vec_last_hip_error',
+    'meda_vec_get_map', 'meda_vec_set_map', 'meda_vec_launch_shape', 'meda_vec_strerror', 'meda_vec_last_hip_error',
 ]
 
 
@@ -128,6 +129,7 @@ def meda_vec():
     lib.meda_vec_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.meda_vec_get_map.argtypes = [vp, i32, vp, vp]
     lib.meda_vec_set_map.argtypes = [vp, i32, vp, vp]
+    lib.meda_vec_launch_shape.argtypes = [vp, C.POINTER(C.c_int32 * 2)]
     lib.meda_vec_strerror.argtypes = [i32]
     lib.meda_vec_strerror.restype = C.c_char_p
     lib.meda_vec_last_hip_error.argtypes = []

@@ -51,6 +51,39 @@ def common_parser():
     return p
 
 
+def vectorise_schedule(args, ref, world=1):
+    """Map the reference's per-2-episode training schedule onto rounds of n_envs episodes.
+
+    The reference does `train_time` learns of `batch_size` episodes after every `n_episodes` collected episodes
+    (train.py:62-78), i.e. 64 sampled episodes per collected one for 4d.yaml.  One vectorised round collects
+    n_envs x world episodes; keeping that ratio would mean ~2000 learns per round ("Update-to-data
+    ratio"), so the vectorised loop runs `train_time` (default 4) learns of `batch_size` (default max(yaml, n_envs/8))
+    episodes per round instead, and every horizon the reference measures in ENV STEPS is stretched so that it spans
+    the same number of LEARNS as in the reference:
+
+        scale = (n_envs * ref.train_time) / (ref.n_episodes * train_time)   (--step_scale overrides; 1 = raw yaml numbers)
+        anneal_steps            *= scale            (epsilon anneals on the env steps of a rank's OWN chips)
+        n_steps, evaluate_cycle *= scale * world    (Trainer.time_steps counts the env steps of ALL ranks)
+
+    `target_update_cycle` is counted in learns and stays (200).  With the defaults (dmfb, 4 droplets, 4096 chips):
+    scale 512, epsilon reaches min_epsilon after ~3 750 learns as in the reference, ~50 000 learns in all, one
+    checkpoint per ~2 500 learns."""
+    if args.train_time is None:
+        args.train_time = 4
+    if args.batch_size is None:
+        args.batch_size = max(ref['batch_size'], args.n_envs // 8)
+    if args.anneal_steps is None:
+        args.anneal_steps = ref['anneal_steps']
+    scale = args.step_scale
+    if scale is None:
+        scale = (args.n_envs * ref['train_time']) / float(ref['n_episodes'] * max(1, args.train_time))
+    args.step_scale = scale
+    args.n_steps = int(round(args.n_steps * scale * world))
+    args.anneal_steps = int(round(args.anneal_steps * scale))
+    args.evaluate_cycle = int(round(args.evaluate_cycle * scale * world))
+    return args
+
+
 def set_default(args):
     """common/arguments.py:57-81."""
     if args.name == 'dmfb':
@@ -79,11 +112,23 @@ def get_train_args(argv=None):
     p.add_argument('--replay_dir', type=str, default='')
     p.add_argument('--evaluate_cycle', type=int, default=100000)
     p.add_argument('--online_eval', default=True, action='store_false')
+    # vectorised cadence (None = derived by vectorise_schedule)
+    p.add_argument('--train_time', type=int, default=None, help='learns per round of n_envs episodes (default 4)')
+    p.add_argument('--batch_size', type=int, default=None, help='episodes per learn (default max(yaml value, n_envs/8))')
+    p.add_argument('--anneal_steps', type=int, default=None, help='epsilon anneal horizon in reference env steps (default: yaml)')
+    p.add_argument('--step_scale', type=float, default=None,
+                   help='factor applied to n_steps, anneal_steps and evaluate_cycle (default: keep the reference\'s horizons '
+                        'measured in learns; 1 = raw reference numbers)')
     args = set_default(p.parse_args(argv))
+    given = {k: getattr(args, k) for k in ('train_time', 'batch_size', 'anneal_steps')}
+    ref = dict(TRAIN_PARAS[(args.name, args.drop_num)])
     args.__dict__.update(_COMMON)
-    args.__dict__.update(TRAIN_PARAS[(args.name, args.drop_num)])
+    args.__dict__.update(ref)
+    args.__dict__.update(given)
     args.n_steps = args.n_steps * 100000
-    return args
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1')) if args.dist else 1
+    return vectorise_schedule(args, ref, world)
 
 
 def get_evaluate_args(argv=None):

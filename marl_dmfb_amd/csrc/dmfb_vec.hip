@@ -447,6 +447,12 @@ int dmfb_vec_set_map(dmfb_vec *h, int which, const double *d_buf, void *stream) 
     return DMFB_OK;
 }
 
+int dmfb_vec_launch_shape(const dmfb_vec *h, int32_t out[4]) {
+    if (!h || !out) return DMFB_ERR_BAD_ARG;
+    out[0] = h->T_fused; out[1] = h->T_obs; out[2] = h->split_min; out[3] = kStepOnlyTile;
+    return DMFB_OK;
+}
+
 int dmfb_vec_zoom_lut(const dmfb_vec *h, int8_t *host_out) {
     if (!h || !host_out) return DMFB_ERR_BAD_ARG;
     memcpy(host_out, h->zoom_host, sizeof(h->zoom_host));

@@ -508,6 +508,12 @@ int meda_vec_set_map(meda_vec *h, int which, const double *d_buf, void *stream) 
     return MEDA_OK;
 }
 
+int meda_vec_launch_shape(const meda_vec *h, int32_t out[2]) {
+    if (!h || !out) return MEDA_ERR_BAD_ARG;
+    out[0] = kBlock; out[1] = h->dc.T;
+    return MEDA_OK;
+}
+
 const char *meda_vec_strerror(int code) {
     switch (code) {
     case MEDA_OK: return "ok";

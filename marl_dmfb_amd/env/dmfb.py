@@ -215,6 +215,12 @@ class VecDMFB:
         t = t.expand(self.n_envs, self.width, self.length).contiguous()
         _check(self.lib.dmfb_vec_set_map(self.h, MAPS[which], _ptr(t), self._stream()))
 
+    def launch_shape(self):
+        """Chips per workgroup of the launches the handle makes (include/dmfb_vec.h: dmfb_vec_launch_shape)."""
+        out = (C.c_int32 * 4)()
+        _check(self.lib.dmfb_vec_launch_shape(self.h, C.byref(out)))
+        return {'fused_tile': out[0], 'observe_tile': out[1], 'split_min_envs': out[2], 'step_only_tile': out[3]}
+
     def zoom_lut(self):
         out = np.zeros((2, 511), np.int8)
         _check(self.lib.dmfb_vec_zoom_lut(self.h, out.ctypes.data_as(C.c_void_p)))

@@ -154,6 +154,12 @@ class VecMEDA:
         _check(self.lib.meda_vec_observe(self.h, _ptr(self._dev(mask, torch.uint8)), _ptr(obs), self._stream()))
         return obs
 
+    def launch_shape(self):
+        """Chips per workgroup of the launches the handle makes (include/meda_vec.h: meda_vec_launch_shape)."""
+        out = (C.c_int32 * 2)()
+        _check(self.lib.meda_vec_launch_shape(self.h, C.byref(out)))
+        return {'step_tile': out[0], 'observe_tile': out[1]}
+
     def get_state(self):
         E, n, dev = self.n_envs, self.n_agents, self.device
         pos = torch.empty((E, n, 2), dtype=torch.int32, device=dev)

@@ -89,6 +89,10 @@ class VDN:
         self.last_loss = None
         self.last_grad_norm = None
         self._flat = None
+        # scalars a caller wants summed over the ranks without a collective of their own (Trainer: the env-step count of the
+        # round): float32 tensor set before learn(); the next gradient all-reduce carries it and leaves the sums here
+        self.ride_along = None
+        self.ride_along_sum = None
         self.dist = bool(getattr(args, 'dist', False)) and torch.distributed.is_available() \
             and torch.distributed.is_initialized() \
             and (torch.distributed.get_world_size() > 1 or bool(getattr(args, 'force_dist', False)))
@@ -112,12 +116,8 @@ class VDN:
             off += p.numel()
         self.target_rnn.load_state_dict(self.eval_rnn.state_dict())
 
-    def _allreduce_grads(self, mask_sum):
-        """ONE collective per learn step: [all gradients of the un-normalised loss, mask count].  Flatten = one
-        concatenation, un-flatten = one scale + one multi-tensor copy, so a rank adds ~4 launches to the all-reduce."""
-        params = [p for p in self.eval_parameters if p.grad is not None]
-        n = sum(p.numel() for p in params)
-        flat = torch.cat([p.grad.reshape(-1) for p in params] + [mask_sum.reshape(1).to(torch.float32)])
+    def all_reduce_sum(self, flat):
+        """In-place SUM all-reduce of a flat tensor; returns it."""
         if flat.is_cuda and torch.distributed.get_backend() == 'gloo':
             # rehearsal only (several ranks sharing one GPU over gloo): stage through the host
             host = flat.cpu()
@@ -125,8 +125,24 @@ class VDN:
             flat.copy_(host)
         else:
             torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
+        return flat
+
+    def _allreduce_grads(self, mask_sum):
+        """ONE collective per learn step: [all gradients of the un-normalised loss, mask count, ride-along scalars].
+        Flatten = one concatenation, un-flatten = one scale + one multi-tensor copy, so a rank adds ~4 launches to the
+        all-reduce."""
+        params = [p for p in self.eval_parameters if p.grad is not None]
+        n = sum(p.numel() for p in params)
+        parts = [p.grad.reshape(-1) for p in params] + [mask_sum.reshape(1).to(torch.float32)]
+        extra = self.ride_along
+        if extra is not None:
+            parts.append(extra.reshape(-1).to(device=mask_sum.device, dtype=torch.float32))
+        flat = self.all_reduce_sum(torch.cat(parts))
+        if extra is not None:
+            self.ride_along_sum = flat[n + 1:].clone()
+            self.ride_along = None
         total = flat[n].clone()
-        flat.div_(total)
+        flat[:n].div_(total)
         views, off = [], 0
         for p in params:
             views.append(flat[off:off + p.numel()].view_as(p))

@@ -1,10 +1,16 @@
 """Training driver with the loop shape of the reference's Trainer.run (train.py:32-94; the stale
 runner.py:29-77 has the same shape): collect episodes -> store -> train_time x (sample, learn),
-checkpoint every `evaluate_cycle` env steps.
+checkpoint (and optionally evaluate) every `evaluate_cycle` env steps, final save + evaluation.
 
 One `generate_episode()` here plays one episode on every chip of the batch, so a round collects
 n_envs episodes instead of the reference's n_episodes (2); the learn cadence is therefore stated
-explicitly: `train_time` learns of `batch_size` episodes per round (args.train_time/batch_size)."""
+explicitly: `train_time` learns of `batch_size` episodes per round (args.train_time/batch_size).
+
+Data parallel (`args.dist`, one rank per GPU): every rank owns its shard of chips and its replay shard.
+`time_steps` is the GLOBAL count of collected env steps -- each rank's count rides in the flat gradient
+all-reduce of the round's first learn -- so every rank takes the same stop/checkpoint decisions and
+runs the same number of learns; only rank 0 writes checkpoints and result files."""
+import copy
 import os
 import time
 
@@ -13,7 +19,7 @@ import torch
 
 from .agent.agent import Agents
 from .common.replay_buffer import ReplayBuffer
-from .common.rollout import RolloutWorker
+from .common.rollout import Evaluator, RolloutWorker
 
 
 class Trainer:
@@ -30,70 +36,128 @@ class Trainer:
             args.fov, args.width, args.length, args.drop_num, args.block_num)
         self.time_steps = 0
         self.trained_times = 0
+        self.dist = bool(self.agents.policy.dist)
+        self.rank = torch.distributed.get_rank() if self.dist else 0
+        self.saves = []  # (time_steps, evaluate index or None) of every checkpoint written, for tests/logs
 
     def collect_and_learn(self):
-        """One round of the outer loop (train.py:59-78).  Returns env steps played this round."""
+        """One round of the outer loop (train.py:59-78).  Returns env steps played this round (this rank)."""
         _, steps, _, success, episode = self.rolloutWorker.generate_episode()
         played = int((~episode['padded']).sum().item())
         self.buffer.store_episode(episode)
+        local = steps.sum()  # failure-inflated count, as train.py:65
+        pol = self.agents.policy
+        if self.dist:  # this rank's count travels with the gradients of the first learn (two exactly representable floats)
+            pol.ride_along = torch.stack([local // 4096, local % 4096]).to(torch.float32)
+            pol.ride_along_sum = None
         for _ in range(self.args.train_time):
             mini_batch = self.buffer.sample(min(self.buffer.current_size, self.args.batch_size))
             self.agents.train(mini_batch, self.trained_times)
             self.trained_times += 1
-        self.time_steps += int(steps.sum().item())  # failure-inflated count, as train.py:65
+        if self.dist:
+            if pol.ride_along_sum is None:  # no learn ran this round (train_time == 0): reduce the count by itself
+                pol.ride_along_sum = pol.all_reduce_sum(pol.ride_along)
+                pol.ride_along = None
+            hi, lo = (int(round(v)) for v in pol.ride_along_sum.tolist())
+            self.time_steps += hi * 4096 + lo
+        else:
+            self.time_steps += int(local.item())
         return played
 
+    def _evaluate_and_record(self, evaluator=None):
+        ev = evaluator or self.rolloutWorker
+        r, s, c, ok = ev.evaluate(max(1, self.args.evaluate_task // self.env.n_envs))
+        self.episode_rewards.append(r); self.episode_steps.append(s)
+        self.episode_constraints.append(c); self.success_rate.append(ok)
+
+    def _save_model(self, k=None):
+        if self.rank == 0:
+            self.agents.policy.save_model(k)
+        self.saves.append((self.time_steps, k))
+
     def run(self, online_evaluate=False):
+        """train.py:32-94: checkpoint `k` (and evaluation k) when time_steps first reaches k * evaluate_cycle; after the
+        loop the final checkpoint `{i}_rnn_net_params.pkl`, one more evaluation and the result files (or, with
+        online_evaluate off, evaluate_total over the saved checkpoints)."""
         evaluate_steps = -1
         start = time.time()
         while self.time_steps < self.args.n_steps:
             if self.time_steps // self.args.evaluate_cycle > evaluate_steps:
                 evaluate_steps += 1
                 self.time_cost.append(time.time() - start)
-                self.agents.policy.save_model(evaluate_steps)
+                self._save_model(evaluate_steps)
                 if online_evaluate:
-                    r, s, c, ok = self.rolloutWorker.evaluate(max(1, self.args.evaluate_task // self.env.n_envs))
-                    self.episode_rewards.append(r); self.episode_steps.append(s)
-                    self.episode_constraints.append(c); self.success_rate.append(ok)
+                    self._evaluate_and_record()
                     self.train_data_save()
             self.collect_and_learn()
-        self.agents.policy.save_model()
+        self._save_model()
         self.time_cost.append(time.time() - start)
+        if online_evaluate:
+            self._evaluate_and_record()
+            self.train_data_save()
+        else:
+            self.evaluate_total(evaluate_steps + 1)
+
+    def evaluate_total(self, n_saved=None):
+        """train.py:96-118: greedy evaluation of every saved checkpoint, then of the final one.  The reference counts
+        n_steps // evaluate_cycle checkpoints; the failure-inflated step count can end the loop before the last of
+        them was written, so the count actually saved is used when known."""
+        args = copy.copy(self.args)
+        args.load_model, args.dist = True, False
+        n = args.n_steps // args.evaluate_cycle if n_saved is None else n_saved
+        names = ['{}_{}_'.format(args.ith_run, k) for k in range(n)] + ['{}_'.format(args.ith_run)]
+        if self.dist:
+            torch.distributed.barrier()  # rank 0 has written the files
+        for name in names:
+            args.load_model_name = name
+            self._evaluate_and_record(Evaluator(self.env, Agents(args), args.episode_limit))
+        self.train_data_save()
 
     def train_data_save(self):
-        """File names of train.py:145-158."""
+        """File names of train.py:145-158 (prefix '{alg}_env(W,L,n,blocks,fov,stall)' inside save_path)."""
+        if self.rank != 0:
+            return
         os.makedirs(self.save_path, exist_ok=True)
-        i = self.args.ith_run
-        np.save(self.save_path + '/Rewards_{}'.format(i), self.episode_rewards)
-        np.save(self.save_path + '/steps_{}'.format(i), self.episode_steps)
-        np.save(self.save_path + '/constraints_{}'.format(i), self.episode_constraints)
-        np.save(self.save_path + '/success_rate_{}'.format(i), self.success_rate)
-        np.save(self.save_path + '/runtime_{}'.format(i), self.time_cost)
+        a = self.args
+        prefix = self.save_path + '/{}'.format(a.alg) + '_env({},{},{},{},{},{})'.format(
+            a.width, a.length, a.drop_num, a.block_num, a.fov, a.stall)
+        i = a.ith_run
+        np.save(prefix + 'Rewards_{}'.format(i), self.episode_rewards)
+        np.save(prefix + 'steps_{}'.format(i), self.episode_steps)
+        np.save(prefix + 'constraints_{}'.format(i), self.episode_constraints)
+        np.save(prefix + 'success_rate_{}'.format(i), self.success_rate)
+        np.save(prefix + 'runtime_{}'.format(i), self.time_cost)
 
 
 def main(argv=None):
     """`python -m marl_dmfb_amd.train dmfb --drop_num=4 --fov=9 [--n_envs 4096] [--dist]` -- the reference's
-    `python train.py dmfb --drop_num=4 --fov=9` (train.py:161-169) on the vectorised HIP env."""
+    `python train.py dmfb --drop_num=4 --fov=9` (train.py:161-169) on the vectorised HIP env.  The schedule lengths
+    are rescaled for the vectorised cadence by common/arguments.py:vectorise_schedule (see there)."""
     import torch.distributed as dist
     from .common.arguments import get_train_args
     args = get_train_args(argv)
     rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
-    if args.dist and world > 1:
+    use_dist = bool(args.dist and world > 1)
+    if use_dist:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    if args.name == 'dmfb':
-        from .env.dmfb import VecDMFB
-        env = VecDMFB(args.width, args.length, args.drop_num, args.block_num, fov=args.fov, stall=args.stall,
-                      n_envs=args.n_envs, seed=args.seed, env_id0=rank * args.n_envs)
-    else:
-        from .env.meda import VecMEDA
-        env = VecMEDA(args.width, args.length, args.drop_num, fov=args.fov, n_envs=args.n_envs, seed=args.seed,
-                      env_id0=rank * args.n_envs, version=2 if args.version == '0.2' else 0)
-    args.__dict__.update(env.get_env_info())
-    args.device = str(env.device)
-    args.buffer_size = max(args.buffer_size, 4 * args.n_envs)
-    Trainer(env, args).run(online_evaluate=args.online_eval)
+    try:
+        if args.name == 'dmfb':
+            from .env.dmfb import VecDMFB
+            env = VecDMFB(args.width, args.length, args.drop_num, args.block_num, fov=args.fov, stall=args.stall,
+                          n_envs=args.n_envs, seed=args.seed, env_id0=rank * args.n_envs)
+        else:
+            from .env.meda import VecMEDA
+            env = VecMEDA(args.width, args.length, args.drop_num, fov=args.fov, n_envs=args.n_envs, seed=args.seed,
+                          env_id0=rank * args.n_envs, version=2 if args.version == '0.2' else 0)
+        args.__dict__.update(env.get_env_info())
+        args.device = str(env.device)
+        args.buffer_size = max(args.buffer_size, 4 * args.n_envs)
+        Trainer(env, args).run(online_evaluate=args.online_eval)
+    finally:
+        if use_dist:
+            dist.destroy_process_group()
 
 
 if __name__ == '__main__':

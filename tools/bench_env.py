@@ -34,12 +34,37 @@ def algo_bytes(cfg, ext_uniforms=False):
     return writes + reads + state
 
 
-def run(name, E, iters, autoreset=True):
+def launch_labels(name, cfg, env, E):
+    """(kernel name | grid size) of the launches this configuration makes -> key in profiles/traffic.json and the
+    algorithmic bytes of one launch (tools/reduce_profiles.py traffic)."""
+    n, fov, W, L = cfg['n_agents'], cfg['fov'], cfg['width'], cfg['length']
+    wgs = lambda tile: (E + tile - 1) // tile * 256
+    sh = env.launch_shape()
+    out = {}
+    if cfg['meda']:
+        ob = n * (4 * fov * fov + 2)
+        out['medak::k_meda_step<%d>|%d' % (n, wgs(sh['step_tile']))] = {'key': 'k_meda_step_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (algo_bytes(cfg) - ob) * E}
+        out['(anonymous namespace)::k_meda_observe|%d' % wgs(sh['observe_tile'])] = {'key': 'k_meda_observe_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (ob + 5 * n + 8) * E}
+        return out
+    ob = n * (3 * fov * fov + 2)
+    maps = 'true' if cfg.get('b_degrade') else 'false'
+    if E >= sh['split_min_envs']:
+        out['dmfbk::k_step<%d, %s>|%d' % (n, maps, wgs(sh['step_only_tile']))] = {'key': 'k_step_only_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (algo_bytes(cfg) - ob) * E}
+    else:
+        out['dmfbk::k_step<%d, %s>|%d' % (n, maps, wgs(sh['fused_tile']))] = {'key': 'k_step_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': algo_bytes(cfg) * E}
+    out['dmfbk::k_observe<%d>|%d' % (n, wgs(sh['observe_tile']))] = {'key': 'k_observe_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (ob + 5 * n + 8) * E}
+    return out
+
+
+def run(name, E, iters, autoreset=True, observe=False, labels=None):
     cfg = dict(CFGS[name])
     meda = cfg.pop('meda', False)
     env = (VecMEDA if meda else VecDMFB)(n_envs=E, seed=0, **cfg)
     cfg['meda'] = meda
     env.reset()
+    if labels is not None:
+        for k, v in launch_labels(name, cfg, env, E).items():
+            labels.setdefault(k, []).append(v)
     g = torch.Generator(device='cuda').manual_seed(0)
     acts = [torch.randint(0, 9 if meda else 5, (E, cfg['n_agents']), device='cuda', generator=g, dtype=torch.int8) for _ in range(8)]
     for i in range(10):
@@ -53,18 +78,39 @@ def run(name, E, iters, autoreset=True):
     torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / iters
     b = algo_bytes(cfg)
-    return dict(cfg=name, E=E, us_per_launch=round(ms * 1e3, 2), env_steps_per_s=round(E / ms * 1e3),
-                algo_GBps=round(E * b / ms / 1e6, 1), frac_of_8TBps=round(E * b / ms / 1e6 / 8000, 4))
+    out = dict(cfg=name, E=E, us_per_launch=round(ms * 1e3, 2), env_steps_per_s=round(E / ms * 1e3),
+               algo_bytes_per_env_step=b, algo_GBps=round(E * b / ms / 1e6, 1), frac_of_8TBps=round(E * b / ms / 1e6 / 8000, 4))
+    if observe:  # the FOV-gather kernel alone, back-to-back launches
+        env.observe()
+        torch.cuda.synchronize()
+        t0.record()
+        for i in range(iters):
+            env.observe()
+        t1.record()
+        torch.cuda.synchronize()
+        ms = t0.elapsed_time(t1) / iters
+        n, fov = cfg['n_agents'], cfg['fov']
+        fb = n * ((4 if meda else 3) * fov * fov + 2) + 5 * n + 8
+        out['observe'] = dict(us_per_launch=round(ms * 1e3, 2), algo_bytes_per_env=fb, algo_GBps=round(E * fb / ms / 1e6, 1),
+                              frac_of_8TBps=round(E * fb / ms / 1e6 / 8000, 4))
+    return out
 
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--cfg', default='A,D,E,M30,M60')
     ap.add_argument('--sizes', default='4096,65536,262144,1048576')
+    ap.add_argument('--msizes', default=None, help='batch sizes for the MEDA configurations (default: --sizes up to 65536)')
     ap.add_argument('--iters', type=int, default=200)
+    ap.add_argument('--observe', action='store_true', help='also time the observation kernel alone')
+    ap.add_argument('--labels', default=None, help='write the (kernel|grid) -> traffic.json key table of this run here')
     a = ap.parse_args()
+    labels = {} if a.labels else None
     for name in a.cfg.split(','):
-        for E in [int(s) for s in a.sizes.split(',')]:
+        sizes = a.msizes if (name.startswith('M') and a.msizes) else a.sizes
+        for E in [int(s) for s in sizes.split(',')]:
             if name != 'A' and E > 262144 or name.startswith('M') and E > 65536:
                 continue
-            print(json.dumps(run(name, E, a.iters)), flush=True)
+            print(json.dumps(run(name, E, a.iters, observe=a.observe, labels=labels)), flush=True)
+    if a.labels:
+        json.dump(labels, open(a.labels, 'w'), indent=1)

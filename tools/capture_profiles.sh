@@ -1,0 +1,42 @@
+#!/bin/bash
+# Capture the measurement records of a round on the MI355X box (run through gpurun from the repo root):
+#   tools/capture_profiles.sh r02 [quick]
+# Writes raw rocprofv3 output under gpurun_out/<round>/ (scratch) and the reduced summaries under
+# gpurun_out/<round>/summary/ -- copy those into profiles/<round>/ and profiles/traffic.json and commit them.
+# Counter passes are separate runs with --kernel-trace only (gpurun refuses --pmc combined with other trace domains).
+set -eo pipefail
+ROUND=${1:-r02}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$ROUND
+SUM=$OUT/summary
+mkdir -p "$SUM"
+export TMPDIR=/tmp
+cd /tmp
+
+echo "== bench.py (plain) ==" ; date
+python3 $REPO/bench.py > $SUM/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
+cat $SUM/bench.json
+
+echo "== bench.py under rocprofv3 --kernel-trace --stats ==" ; date
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $REPO/bench.py --steps 10 --warmup 3 --no_cpu_baseline \
+    > $SUM/bench_under_rocprof.json 2> $OUT/bench_trace.err
+python3 $REPO/tools/reduce_profiles.py trace $OUT/bench_trace $SUM/bench_kernels_by_grid.csv
+cp $(ls $OUT/bench_trace/*/*_kernel_stats.csv | head -1) $SUM/bench_kernel_stats.csv
+
+echo "== env tiers (plain) ==" ; date
+python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60 --sizes 4096,65536,262144 --iters 100 --observe > $SUM/env_tiers.jsonl
+cat $SUM/env_tiers.jsonl
+
+echo "== env kernels under rocprofv3 --kernel-trace ==" ; date
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/env_trace -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60 \
+    --sizes 4096,262144 --msizes 4096,65536 --iters 40 --observe > $OUT/env_trace.log 2>&1
+python3 $REPO/tools/reduce_profiles.py trace $OUT/env_trace $SUM/env_kernels_by_grid.csv '(dmfbk|medak)::'
+
+echo "== HBM traffic counters ==" ; date
+# sizes 4096 + 262144 (MEDA: 4096 + 65536) only: the fused 4096-chip launch and the 65536-chip step-only launch share a grid size
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60 \
+    --sizes 4096,262144 --msizes 4096,65536 --iters 24 --observe --labels $OUT/labels.json > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60 \
+    --sizes 4096,262144 --msizes 4096,65536 --iters 24 --observe > $OUT/pmc_write.log 2>&1
+python3 $REPO/tools/reduce_profiles.py traffic $OUT/pmc_fetch $OUT/pmc_write $SUM/traffic.json $OUT/labels.json
+echo "== done ==" ; date
