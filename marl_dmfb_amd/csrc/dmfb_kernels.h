@@ -32,6 +32,7 @@
 namespace dmfbk {
 
 constexpr int kBlock = 256;
+constexpr int kObsBlock = 256;  // threads per workgroup of k_observe (two lanes per observation row, see scatter_rows)
 constexpr int kWave = 64;
 // Rejection sampling is bounded so that every wave terminates: after 2^22 rejected attempts the
 // last attempt's points are kept as they are (same rule in the oracle; never hit by legal configs
@@ -47,6 +48,7 @@ struct DevCfg {
     int T_obs;  // chips per workgroup of k_observe
     uint32_t k0, k1, env_id0;
     uint32_t fov_magic;  // ceil(2^32 / fov): k / fov == __umulhi(k, fov_magic) for the ranges used (fov >= 2)
+    int nq;              // 8-byte words per band image, padded to a multiple of 12 (see DevPtrs::band)
     double per_healthy;
 };
 
@@ -58,7 +60,28 @@ struct DevPtrs {
     uint16_t *usage;   // [E][W*L]
     const int8_t *zoom;  // [2][511] direction zoom table
     uint32_t *blocks;    // [n_blocks][E] x_min | x_max<<8 | y_min<<16 | y_max<<24, or nullptr
+    // Observation tables, copied into LDS by every workgroup that builds observations (table_words() 8-byte words):
+    //   [axis 2][pattern 2*hf+1][nq] out-of-chip band images of layer 2 (dmfb.py:428-439): the fov*fov layer bytes of
+    //   one axis' band, zero padded to nq words.  Pattern 0 = window inside the chip on that axis, p in 1..hf = `p`
+    //   leading window rows/columns outside, hf+p = `p` trailing ones.  A row ORs (X image | Y image), shifted to the byte
+    //   phase of its layer in LDS, into the zeroed tile with aligned 8-byte LDS atomics.
+    //   then 128 words = the direction zoom table int8[2][511] (dmfb.py:444-453), padded to 1024 bytes.
+    const unsigned long long *band;
+    unsigned long long *dbg;  // diagnostic builds (-DDMFB_STAMPS) only: per-workgroup phase time stamps of k_observe
 };
+
+// In-kernel time stamps exist only in the diagnostic build (make stamps -> lib/libdmfb_vec_stamps.so, tools/exp_stamps.py);
+// the shipped kernels contain none.
+#ifdef DMFB_STAMPS
+#define DMFB_STAMP(k)                                                                               \
+    do {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    } while (0)
+#else
+#define DMFB_STAMP(k) do { } while (0)
+#endif
 
 // ---- packed record layout -------------------------------------------------------------------
 // NP = ceil(N/2) words of positions (agent i: word i>>1, half i&1, value x | y<<8),
@@ -71,6 +94,7 @@ template <int N> struct Rec {
 constexpr uint32_t FLAG_DUP = 1u;  // two droplets share a cell (only reachable through set_task)
 
 __host__ __device__ inline int rec_words(int n) { return 2 * ((n + 1) / 2) + 5; }
+__host__ __device__ inline int table_words(int hf, int nq) { return 2 * (2 * hf + 1) * nq + 128; }
 
 // ---- Philox4x32-10 ---------------------------------------------------------------------------
 __device__ __forceinline__ void philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
@@ -281,25 +305,35 @@ __device__ __forceinline__ void gen_degrade_env(const DevCfg &c, const DevPtrs &
 // ---- LDS tile -----------------------------------------------------------------------------------
 struct Tile {
     int8_t *obs;       // [T][N][obs_len], 16-byte aligned (absent in the step-only launch)
-    uint16_t *pos;     // [T][N]
-    uint16_t *goal;    // [T][N]
+    uint32_t *pos;     // [T][N] x | y << 16 (two int16 lanes: the window tests use packed 16-bit arithmetic)
+    uint32_t *goal;    // [T][N]
     uint8_t *flag;     // [T] per-env flag (ended / masked)
+    unsigned long long *tab;  // LDS copy of DevPtrs::band (band images, then the zoom table)
 };
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 // LDS bytes of a workgroup: obs block (0 for the step-only launch) + pos/goal + flags
 // The obs block sits in LDS at the SAME 16-byte phase as its destination in HBM (shift = offset & 15), so
 // the body of a tile streams out with aligned 16-byte accesses for ANY tile size (16 bytes of slack).
-__host__ __device__ inline size_t tile_lds_bytes(int T, int n, int obs_len, bool with_obs) {
-    return (with_obs ? align16((size_t)T * n * obs_len + 16) : 0) + (size_t)T * n * 4 + align16((size_t)T);
+__host__ __device__ inline size_t tile_lds_bytes(int T, int n, int obs_len, bool with_obs, int tab_words) {
+    // observation tile + tables, positions/goals, flags, and (observation kernel) a second positions/goals buffer
+    return (with_obs ? align16((size_t)T * n * obs_len + 16) + (size_t)tab_words * 8 + (size_t)T * n * 8 : 0) + (size_t)T * n * 8 +
+           align16((size_t)T);
 }
-__device__ __forceinline__ Tile carve(unsigned char *smem, int T, int n, int obs_len, bool with_obs, int shift = 0) {
+__device__ __forceinline__ Tile carve(unsigned char *smem, int T, int n, int obs_len, bool with_obs, int tab_words, int shift = 0) {
     Tile t;
     t.obs = (int8_t *)smem + shift;
-    const size_t off = with_obs ? align16((size_t)T * n * obs_len + 16) : 0;
-    t.pos = (uint16_t *)(smem + off);
+    size_t off = with_obs ? align16((size_t)T * n * obs_len + 16) : 0;
+    t.tab = (unsigned long long *)(smem + off);
+    if (with_obs) off += (size_t)tab_words * 8;
+    t.pos = (uint32_t *)(smem + off);
     t.goal = t.pos + (size_t)T * n;
     t.flag = (uint8_t *)(t.goal + (size_t)T * n);
     return t;
+}
+// copy the observation tables into LDS (any subset of the workgroup's threads; a barrier follows before they are read)
+__device__ __forceinline__ void load_tables(const DevCfg &c, const DevPtrs &p, const Tile &t, int tid, int nthreads) {
+    const int words = table_words(c.hf, c.nq);
+    for (int i = tid; i < words; i += nthreads) t.tab[i] = p.band[i];
 }
 
 __device__ __forceinline__ void zero_tile(unsigned char *smem, int bytes16, int tid, int nthreads) {
@@ -308,37 +342,124 @@ __device__ __forceinline__ void zero_tile(unsigned char *smem, int bytes16, int 
     for (int i = tid; i < bytes16; i += nthreads) p[i] = z;
 }
 
-// getOneObs (dmfb.py:395-457) for every (env, agent) row of the tile: scatter the non-zero cells.
-// Pass 1: one lane per row (layers 0/1 + direction).  Pass 2: one lane per (row, window row x) for
-// the out-of-chip bands of layer 2.
+// ---- packed int16 pairs (x in the low half, y in the high half) ------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_clamp_i(uint32_t a, uint32_t lo, uint32_t hi) {
+    s16x2 v = __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, lo));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(v, __builtin_bit_cast(s16x2, hi)));
+}
+__device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) * 0x10001u; }
+__device__ __forceinline__ uint32_t to_xy(uint32_t byte_pair) { return (byte_pair & 0xffu) | ((byte_pair & 0xff00u) << 8); }
+
+// getOneObs (dmfb.py:395-457) for the tile, phase 1 of 2 (runs between the zero-fill and the byte stores of
+// scatter_rows, a barrier on either side): layer 2, the out-of-chip bands (dmfb.py:428-439).  One lane per row ORs
+// the row's band image -- X-axis image | Y-axis image from DevPtrs::band, selected by how far the window hangs over the
+// chip border and by the byte phase of the row's layer in LDS -- into the zeroed tile with aligned 8-byte LDS atomics
+// (neighbouring rows share the 8-byte words at their seams, hence atomics; no byte store is in flight in this phase).
 template <int N>
-__device__ __forceinline__ void scatter_tile(const DevCfg &c, const DevPtrs &p, const Tile &t, int tile_base, int tv,
+__device__ __forceinline__ void scatter_bands(const DevCfg &c, const Tile &t, unsigned char *smem, int tv, int tid, int nthreads) {
+    const int hf = c.hf, nq = c.nq, npat = 2 * hf + 1;
+    const int rows = tv * N;
+    const int half = nthreads >> 1;  // lanes [0, half): image words [0, nq/2) of row `lane`; lanes [half, ..): the other half
+    const int obs0 = (int)((unsigned char *)t.obs - smem);  // LDS byte offset of the tile's first row (smem is 16-byte aligned)
+    const int part = tid >= half ? 1 : 0;
+    for (int it = tid - part * half; it < rows; it += half) {
+        const uint32_t pc = t.pos[it];
+        const int cx = (int)(pc & 0xffff), cy = (int)(pc >> 16);
+        const int left = hf - cx, right = hf - (c.W - 1 - cx);
+        const int up = hf - cy, down = hf - (c.L - 1 - cy);
+        const int xpat = left > 0 ? left : (right > 0 ? hf + right : 0);
+        const int ypat = up > 0 ? up : (down > 0 ? hf + down : 0);
+        if ((xpat | ypat) == 0) continue;  // window inside the chip: layer 2 stays zero
+        const int a = obs0 + it * c.obs_len + 2 * c.ff;  // LDS byte offset of this row's layer 2
+        const int sh = (a & 7) * 8;                      // bit shift that moves the image to the layer's byte phase
+        const int qa = part * (nq >> 1), qb = qa + (nq >> 1);  // nq is a multiple of 12: six-word batches
+        unsigned long long *dst = (unsigned long long *)(smem + (a & ~7));
+        const unsigned long long *tx = t.tab + (size_t)xpat * nq, *ty = t.tab + (size_t)(npat + ypat) * nq;
+        unsigned long long prev = qa ? (tx[qa - 1] | ty[qa - 1]) : 0ull;  // its top bytes shift into this lane's first word
+        for (int q0 = qa; q0 < qb; q0 += 6) {  // twelve LDS reads in flight, then the atomics
+            unsigned long long v[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[k] = tx[q0 + k] | ty[q0 + k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const unsigned long long o = sh ? (v[k] << sh) | (prev >> (64 - sh)) : v[k];
+                prev = v[k];
+                if (o) atomicOr(dst + q0 + k, o);
+            }
+        }
+        if (part && sh && (prev >> (64 - sh))) atomicOr(dst + nq, prev >> (64 - sh));
+    }
+}
+
+// phase 2 of 2: layers 0 and 1, the direction bytes and the obstacle blocks -- byte stores.  One lane per row walks the
+// chip's droplets in ascending index (a later droplet overwrites an earlier one as in dmfb.py:404-420); the window and
+// visibility tests run on packed int16 pairs: with D = pos_j - pos_i, droplet j is inside row i's window iff both
+// halves of D + hf lie in [0, fov), i.e. min_u16(D + hf, fov - 1) == D + hf.
+template <int N>
+__device__ __forceinline__ void scatter_rows(const DevCfg &c, const DevPtrs &p, const Tile &t, int tile_base, int tv,
                                              int tid, int nthreads) {
     const int fov = c.fov, hf = c.hf, ff = c.ff;
     const int rows = tv * N;
-    for (int it = tid; it < rows; it += nthreads) {
+    const bool odd = (fov & 1) != 0;  // odd fov: "inside the window" and "visible" (2|d| < fov) are the same test
+    const int hv = (fov - 1) / 2;     // visible <=> |d| <= hv on both axes
+    const uint32_t k_hf = pk2(hf), k_f1 = pk2(fov - 1), k_hv = pk2(hv), k_2hv = pk2(2 * hv);
+    // two lanes per row -- lane r of the first half of the workgroup: layer 0 and the direction bytes, lane r of the second
+    // half: layer 1 -- so the serial walk over the droplets (ascending index inside each layer, as the reference's loops) is
+    // half as long and every wave runs one of the two bodies, not both
+    const int half = nthreads >> 1;
+    const int part = tid >= half ? 1 : 0;
+    for (int it = tid - part * half; it < rows; it += half) {
         const int env = it / N, i = it - env * N;
         int8_t *row = t.obs + (size_t)it * c.obs_len;
-        const uint16_t *pp = t.pos + env * N, *gp = t.goal + env * N;
-        const int cx = pp[i] & 0xff, cy = pp[i] >> 8;
-        const int ox = cx - hf, oy = cy - hf;
+        // every read first (the byte stores below could alias them as far as the compiler knows, which would
+        // serialise an LDS round trip per droplet)
+        uint32_t P[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) {  // layer 0: all droplets inside the window
-            const int x = (pp[j] & 0xff) - ox, y = (pp[j] >> 8) - oy;
-            if (x >= 0 && x < fov && y >= 0 && y < fov) row[x * fov + y] = (int8_t)(j + 1);
-        }
+        for (int j = 0; j < N; ++j) P[j] = t.pos[env * N + j];
+        const uint32_t pi = t.pos[it];
+        const uint32_t org = pk_sub(pi, k_hf);  // window origin (ox, oy)
+        if (part == 0) {
+            const uint32_t d = pk_sub(t.goal[it], pi);  // goal - position, sign-extended halves
+            const int8_t *zoom = (const int8_t *)(t.tab + 2 * (2 * hf + 1) * c.nq);
+            const int8_t dir_x = zoom[(int)(short)(d & 0xffff) + 255], dir_y = zoom[511 + (int)(short)(d >> 16) + 255];
 #pragma unroll
-        for (int j = 0; j < N; ++j) {  // layer 1: clipped goals of the other visible droplets, ascending j
-            const int xj = pp[j] & 0xff, yj = pp[j] >> 8;
-            if (j != i && 2 * iabs(xj - cx) < fov && 2 * iabs(yj - cy) < fov) {
-                int x = (gp[j] & 0xff) - ox, y = (gp[j] >> 8) - oy;
-                x = x < 0 ? 0 : (x > fov - 1 ? fov - 1 : x);
-                y = y < 0 ? 0 : (y > fov - 1 ? fov - 1 : y);
-                row[ff + x * fov + y] = (int8_t)(j + 1);
+            for (int j = 0; j < N; ++j) {  // layer 0: droplet j inside the window
+                const uint32_t w = pk_sub(P[j], org);
+                if (pk_min_u(w, k_f1) == w) row[(w & 0xffff) * fov + (w >> 16)] = (int8_t)(j + 1);
+            }
+            row[3 * ff] = dir_x;
+            row[3 * ff + 1] = dir_y;
+        } else {
+            uint32_t G[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) G[j] = t.goal[env * N + j];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {  // layer 1: the visible droplet's goal clipped into the window
+                bool vis;
+                if (odd) {
+                    const uint32_t w = pk_sub(P[j], org);
+                    vis = pk_min_u(w, k_f1) == w;
+                } else {
+                    const uint32_t v = pk_add(pk_sub(P[j], pi), k_hv);
+                    vis = pk_min_u(v, k_2hv) == v;
+                }
+                if (vis && j != i) {
+                    const uint32_t g = pk_clamp_i(pk_sub(G[j], org), 0u, k_f1);
+                    row[ff + (g & 0xffff) * fov + (g >> 16)] = (int8_t)(j + 1);
+                }
             }
         }
-        row[3 * ff] = p.zoom[(gp[i] & 0xff) - cx + 255];
-        row[3 * ff + 1] = p.zoom[511 + (gp[i] >> 8) - cy + 255];
     }
     if (c.nb > 0) {  // layer 2: blocks, GLOBAL coordinates used as window coordinates (reference quirk dmfb.py:422-426)
         for (int k = tid; k < rows * c.nb; k += nthreads) {
@@ -349,21 +470,6 @@ __device__ __forceinline__ void scatter_tile(const DevCfg &c, const DevPtrs &p, 
             for (int i = x0; i <= x1 && i < fov; ++i)
                 for (int j = y0; j <= y1 && j < fov; ++j) row[i * fov + j] = 1;
         }
-    }
-    for (int k = tid; k < rows * fov; k += nthreads) {  // layer 2: out-of-chip bands (dmfb.py:428-439)
-        const int r = fov == 1 ? k : (int)__umulhi((uint32_t)k, c.fov_magic);
-        const int x = k - r * fov;
-        const uint16_t pc = t.pos[r];
-        const int cx = pc & 0xff, cy = pc >> 8;
-        const int left = hf - cx, right = hf - (c.W - 1 - cx);
-        const int up = hf - cy, down = hf - (c.L - 1 - cy);
-        const bool xb = left > 0 ? (x < left) : (right > 0 ? (x >= fov - right) : false);
-        int y0 = 0, y1 = 0;  // band of y set because of the y bounds
-        if (up > 0) { y0 = 0; y1 = up < fov ? up : fov; }
-        else if (down > 0) { y0 = fov - down < 0 ? 0 : fov - down; y1 = fov; }
-        if (xb) { y0 = 0; y1 = fov; }
-        int8_t *row = t.obs + (size_t)r * c.obs_len + 2 * ff + x * fov;
-        for (int y = y0; y < y1; ++y) row[y] = 1;
     }
 }
 
@@ -376,7 +482,12 @@ __device__ __forceinline__ void copy_tile_out(const Tile &t, int shift, int8_t *
     const int n16 = (bytes - hb) >> 4;
     const uint4 *src = (const uint4 *)(t.obs + hb);
     uint4 *dst = (uint4 *)(gobs + tile_off + hb);
-    for (int i = tid; i < n16; i += nthreads) dst[i] = src[i];
+    int i = tid;
+    for (; i + 3 * nthreads < n16; i += 4 * nthreads) {  // four LDS reads in flight, then four stores
+        const uint4 v0 = src[i], v1 = src[i + nthreads], v2 = src[i + 2 * nthreads], v3 = src[i + 3 * nthreads];
+        dst[i] = v0; dst[i + nthreads] = v1; dst[i + 2 * nthreads] = v2; dst[i + 3 * nthreads] = v3;
+    }
+    for (; i < n16; i += nthreads) dst[i] = src[i];
     for (int b = hb + (n16 << 4) + tid; b < bytes; b += nthreads) gobs[tile_off + b] = t.obs[b];
 }
 
@@ -401,7 +512,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
     const int tid = threadIdx.x;
     const int tile_base = blockIdx.x * T;
     const int shift = want_obs ? (int)(((uintptr_t)a.out.d_obs + (size_t)tile_base * N * c.obs_len) & 15) : 0;
-    const Tile t = carve(smem, T, N, c.obs_len, want_obs, shift);
+    const Tile t = carve(smem, T, N, c.obs_len, want_obs, table_words(c.hf, c.nq), shift);
     const int tv = min(T, E - tile_base);
     const int cells = c.W * c.L;
     const int wave = tid / kWave, lane = tid % kWave;
@@ -411,6 +522,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
     const int step_waves = (T + kWave - 1) / kWave;
 
     if (wave >= step_waves) {
+        if (want_obs) load_tables(c, p, t, tid - step_waves * kWave, kBlock - step_waves * kWave);
         if (want_obs) zero_tile(smem, (int)(align16((size_t)shift + (size_t)tv * N * c.obs_len) >> 4), tid - step_waves * kWave,
                                 kBlock - step_waves * kWave);
     } else {
@@ -636,8 +748,8 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
             if (want_obs) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    t.pos[slot * N + i] = (uint16_t)(r.x[i] | (r.y[i] << 8));
-                    t.goal[slot * N + i] = (uint16_t)(r.gx[i] | (r.gy[i] << 8));
+                    t.pos[slot * N + i] = (uint32_t)r.x[i] | ((uint32_t)r.y[i] << 16);
+                    t.goal[slot * N + i] = (uint32_t)r.gx[i] | ((uint32_t)r.gy[i] << 16);
                 }
             }
             t.flag[slot] = (uint8_t)ended;
@@ -658,7 +770,9 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
         }
     }
     if (!want_obs) return;
-    scatter_tile<N>(c, p, t, tile_base, tv, tid, kBlock);
+    scatter_bands<N>(c, t, smem, tv, tid, kBlock);
+    __syncthreads();
+    scatter_rows<N>(c, p, t, tile_base, tv, tid, kBlock);
     __syncthreads();
     copy_tile_out(t, shift, a.out.d_obs, (size_t)tile_base * N * c.obs_len, tv * N * c.obs_len, tid, kBlock);
 }
@@ -666,46 +780,99 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
 // ---- standalone observation kernel (getObs after reset/restart/set_task, and the second launch of the
 // step-only + observe pair used for large batches) ---------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(kBlock) void k_observe(DevCfg c, DevPtrs p, const uint8_t *mask, int8_t *gobs) {
+__global__ __launch_bounds__(kObsBlock) void k_observe(DevCfg c, DevPtrs p, const uint8_t *mask, int8_t *gobs) {
+    // Persistent workgroups: the grid covers the CUs a few times over and every workgroup walks tiles blockIdx.x,
+    // blockIdx.x + gridDim.x, ...  The observation tables are copied into LDS once per workgroup.  The packed records
+    // run two tiles ahead: while tile k is scattered, the records of tile k+1 sit in registers; just before tile k is
+    // streamed out they are unpacked into the second position buffer and the loads for tile k+2 are issued.  The only
+    // wait for global memory (gfx950 counts loads and stores in one in-order counter) therefore falls where the previous
+    // tile's stores have long drained, never between a tile's stores and the next tile's zero fill.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = c.T_obs, E = c.E;
     const int tid = threadIdx.x;
-    const int tile_base = blockIdx.x * T;
-    const int shift = (int)(((uintptr_t)gobs + (size_t)tile_base * N * c.obs_len) & 15);
-    const Tile t = carve(smem, T, N, c.obs_len, true, shift);
-    const int tv = min(T, E - tile_base);
-    constexpr int NP = Rec<N>::NP;
-    bool all = true, any = true;
-    if (mask) {
-        int cnt = 0;
-        for (int s = 0; s < tv; ++s) cnt += mask[tile_base + s] != 0;
-        all = cnt == tv; any = cnt > 0;
-    }
-    if (!any) return;
-    for (int it = tid; it < tv * NP; it += kBlock) {  // coalesced: consecutive lanes, consecutive chips
-        const int w = it / tv, s = it - w * tv;
-        const int e = tile_base + s;
-        const uint32_t pw = p.st[(size_t)w * E + e], gw = p.st[(size_t)(NP + w) * E + e];
-        t.pos[s * N + 2 * w] = (uint16_t)pw;
-        t.goal[s * N + 2 * w] = (uint16_t)gw;
-        if (2 * w + 1 < N) {
-            t.pos[s * N + 2 * w + 1] = (uint16_t)(pw >> 16);
-            t.goal[s * N + 2 * w + 1] = (uint16_t)(gw >> 16);
-        }
-    }
-    zero_tile(smem, (int)(align16((size_t)shift + (size_t)tv * N * c.obs_len) >> 4), tid, kBlock);
-    __syncthreads();
-    scatter_tile<N>(c, p, t, tile_base, tv, tid, kBlock);
-    __syncthreads();
+    const int ntiles = (E + T - 1) / T;
     const int row_bytes = N * c.obs_len;
-    if (all) {
-        copy_tile_out(t, shift, gobs, (size_t)tile_base * row_bytes, tv * row_bytes, tid, kBlock);
-    } else {
-        for (int s = 0; s < tv; ++s)
-            if (mask[tile_base + s])
-                for (int b = tid; b < row_bytes; b += kBlock)
-                    gobs[(size_t)(tile_base + s) * row_bytes + b] = t.obs[(size_t)s * row_bytes + b];
+    constexpr int NP = Rec<N>::NP;
+    constexpr int kPre = (64 * NP + kObsBlock - 1) / kObsBlock;  // T <= 64: at most this many (word, chip) items per thread
+    uint32_t pw[kPre], gw[kPre];
+    auto prefetch = [&](int tile) {  // coalesced: consecutive lanes, consecutive chips
+        const int base = tile * T, tvn = min(T, E - base);
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) {
+            const int it = tid + k * kObsBlock;
+            pw[k] = gw[k] = 0;
+            if (tile < ntiles && it < tvn * NP) {
+                const int w = it / tvn, s = it - w * tvn;
+                pw[k] = p.st[(size_t)w * E + base + s];
+                gw[k] = p.st[(size_t)(NP + w) * E + base + s];
+            }
+        }
+    };
+    const Tile t0 = carve(smem, T, N, c.obs_len, true, table_words(c.hf, c.nq), 0);
+    // second position/goal buffer behind the tile structure (tile_lds_bytes reserves it for the observation kernel)
+    uint32_t *const pos2 = (uint32_t *)(t0.flag + align16((size_t)T));
+    auto unpack = [&](int tile, uint32_t *pos, uint32_t *goal) {
+        const int tvn = tile < ntiles ? min(T, E - tile * T) : 0;
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) {
+            const int it = tid + k * kObsBlock;
+            if (it < tvn * NP) {
+                const int w = it / tvn, s = it - w * tvn;
+                pos[s * N + 2 * w] = to_xy(pw[k]);
+                goal[s * N + 2 * w] = to_xy(gw[k]);
+                if (2 * w + 1 < N) {
+                    pos[s * N + 2 * w + 1] = to_xy(pw[k] >> 16);
+                    goal[s * N + 2 * w + 1] = to_xy(gw[k] >> 16);
+                }
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    int buf = 0;
+    prefetch(tile);
+    load_tables(c, p, t0, tid, kObsBlock);
+    unpack(tile, t0.pos, t0.goal);
+    prefetch(tile + gridDim.x);
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int tile_base = tile * T;
+        const int shift = (int)(((uintptr_t)gobs + (size_t)tile_base * row_bytes) & 15);
+        Tile t = carve(smem, T, N, c.obs_len, true, table_words(c.hf, c.nq), shift);
+        uint32_t *const npos = buf ? t0.pos : pos2, *const ngoal = npos + (size_t)T * N;
+        if (buf) { t.pos = pos2; t.goal = pos2 + (size_t)T * N; }
+        const int tv = min(T, E - tile_base);
+        // this barrier publishes the positions unpacked during the previous tile and separates its stream-out (LDS
+        // reads) from the zero fill below
+        const int cnt = __syncthreads_count(tid < tv && (!mask || mask[tile_base + tid] != 0));  // T <= 64 <= kObsBlock
+        DMFB_STAMP(0);
+        if (cnt != 0) {  // (uniform) something to refresh in this tile
+            zero_tile(smem, (int)(align16((size_t)shift + (size_t)tv * row_bytes) >> 4), tid, kObsBlock);
+            DMFB_STAMP(1);
+            __syncthreads();
+            DMFB_STAMP(2);
+            scatter_bands<N>(c, t, smem, tv, tid, kObsBlock);
+            __syncthreads();
+            DMFB_STAMP(3);
+            scatter_rows<N>(c, p, t, tile_base, tv, tid, kObsBlock);
+            __syncthreads();
+            DMFB_STAMP(4);
+        }
+        unpack(tile + gridDim.x, npos, ngoal);
+        prefetch(tile + 2 * gridDim.x);
+        DMFB_STAMP(5);
+        if (cnt == tv) {
+            copy_tile_out(t, shift, gobs, (size_t)tile_base * row_bytes, tv * row_bytes, tid, kObsBlock);
+        } else if (cnt != 0) {
+            for (int s = 0; s < tv; ++s)
+                if (mask[tile_base + s])
+                    for (int b = tid; b < row_bytes; b += kObsBlock)
+                        gobs[(size_t)(tile_base + s) * row_bytes + b] = t.obs[(size_t)s * row_bytes + b];
+        }
+        DMFB_STAMP(6);
     }
+#ifdef DMFB_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);  // stores acknowledged
+    DMFB_STAMP(7);
+#endif
 }
 
 // ---- reset / restart / init: one wave per env -------------------------------------------------------

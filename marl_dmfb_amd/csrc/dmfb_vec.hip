@@ -150,14 +150,19 @@ struct dmfb_vec {
     DevPtrs dp;
     int8_t zoom_host[2 * 511];
     int8_t *zoom_dev = nullptr;
+    unsigned long long *band_dev = nullptr;  // DevPtrs::band
     size_t bytes = 0;
     int T_fused = 16;    // chips per workgroup of the fused step+observe launch (<= 64)
     int T_obs = 16;      // chips per workgroup of k_observe
     int split_min = 0;   // batches of at least this many chips use the step-only + observe pair
     int T_min = 16;      // smallest tile pick_tile may choose (DMFB_VEC_MIN_TILE); smaller tiles do not pay off (measured)
+    int n_cu = 256;      // compute units of the device (persistent grid of the observation kernel)
 };
 
 namespace {
+
+// 8-byte words per band image: the fov*fov layer bytes, padded so that the kernel reads them in batches of 12
+int band_words(int fov) { return ((fov * fov + 7) / 8 + 11) / 12 * 12; }
 
 // Tile of the LDS-staged observation: at most 64 chips (wave 0 owns one chip per lane in the fused launch),
 // obs block <= 40 KB so that >= 3-4 workgroups share a CU's 160 KiB, and halved while the grid would not
@@ -167,7 +172,7 @@ int pick_tile(const dmfb_vec *h, int min_groups) {
     int T = 64;
     size_t cap = 40 * 1024;
     if (const char *v = getenv("DMFB_VEC_TILE_KB")) cap = (size_t)atoi(v) * 1024;  // tuning knob
-    while (T > 1 && (size_t)T * row > cap) T >>= 1;
+    while (T > 1 && ((size_t)T * row > cap || tile_lds_bytes(T, h->cfg.n_agents, h->dc.obs_len, true, table_words(h->dc.hf, h->dc.nq)) > 64 * 1024)) T >>= 1;
     while (T > h->T_min && (h->cfg.n_envs + T - 1) / T < min_groups) T >>= 1;
     return T;
 }
@@ -176,8 +181,13 @@ constexpr int kStepOnlyTile = 256;  // step-only launch: every wave of the workg
 
 template <int N> int observe_n(const dmfb_vec *h, const uint8_t *mask, int8_t *obs, hipStream_t s) {
     const int T = h->T_obs;
-    HIP_TRY(launch_observe_n<N>(h->dc, h->dp, mask, obs, (h->cfg.n_envs + T - 1) / T,
-                                tile_lds_bytes(T, N, h->dc.obs_len, true), s));
+    const size_t lds = tile_lds_bytes(T, N, h->dc.obs_len, true, table_words(h->dc.hf, h->dc.nq));
+    // persistent grid: as many workgroups as fit the chip at once (LDS-limited, at most 8 per CU), or one per tile
+    int per_cu = (int)((size_t)160 * 1024 / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    const int ntiles = (h->cfg.n_envs + T - 1) / T;
+    const int grid = ntiles < h->n_cu * per_cu ? ntiles : h->n_cu * per_cu;
+    HIP_TRY(launch_observe_n<N>(h->dc, h->dp, mask, obs, grid, lds, s));
     return DMFB_OK;
 }
 
@@ -190,13 +200,13 @@ template <int N> int step_n(dmfb_vec *h, const StepArgs &a, hipStream_t s) {
         b.out.d_obs = nullptr;
         DevCfg c = h->dc;
         c.T = kStepOnlyTile;
-        HIP_TRY(launch_step_n<N>(c, h->dp, b, (E + c.T - 1) / c.T, tile_lds_bytes(c.T, N, c.obs_len, false), s));
+        HIP_TRY(launch_step_n<N>(c, h->dp, b, (E + c.T - 1) / c.T, tile_lds_bytes(c.T, N, c.obs_len, false, 0), s));
         return observe_n<N>(h, nullptr, a.out.d_obs, s);
     }
     DevCfg c = h->dc;
     const bool with_obs = a.out.d_obs != nullptr;
     c.T = with_obs ? h->T_fused : kStepOnlyTile;
-    HIP_TRY(launch_step_n<N>(c, h->dp, a, (E + c.T - 1) / c.T, tile_lds_bytes(c.T, N, c.obs_len, with_obs), s));
+    HIP_TRY(launch_step_n<N>(c, h->dp, a, (E + c.T - 1) / c.T, tile_lds_bytes(c.T, N, c.obs_len, with_obs, table_words(c.hf, c.nq)), s));
     return DMFB_OK;
 }
 template <int N> int reset_n(dmfb_vec *h, const uint8_t *mask, int mode, hipStream_t s) {
@@ -204,6 +214,14 @@ template <int N> int reset_n(dmfb_vec *h, const uint8_t *mask, int mode, hipStre
     return DMFB_OK;
 }
 
+#ifdef DMFB_STAMPS_ONLY_N  // the diagnostic build instantiates two droplet counts only
+#define DISPATCH_N(n, FN, ...)                                  \
+    switch (n) {                                                \
+    case 4: return FN<4>(__VA_ARGS__);                          \
+    case 10: return FN<10>(__VA_ARGS__);                        \
+    default: return DMFB_ERR_UNSUPPORTED;                       \
+    }
+#else
 #define DISPATCH_N(n, FN, ...)                                  \
     switch (n) {                                                \
     case 1: return FN<1>(__VA_ARGS__);                          \
@@ -224,6 +242,7 @@ template <int N> int reset_n(dmfb_vec *h, const uint8_t *mask, int mode, hipStre
     case 16: return FN<16>(__VA_ARGS__);                        \
     default: return DMFB_ERR_UNSUPPORTED;                       \
     }
+#endif
 
 int launch_step(dmfb_vec *h, const StepArgs &a, hipStream_t s) { DISPATCH_N(h->cfg.n_agents, step_n, h, a, s) }
 int launch_observe(const dmfb_vec *h, const uint8_t *mask, int8_t *obs, hipStream_t s) {
@@ -247,7 +266,8 @@ int dmfb_vec_check_config(const dmfb_vec_config *c) {
         c->n_blocks < 0 || c->n_blocks > DMFB_MAX_BLOCKS)
         return DMFB_ERR_UNSUPPORTED;
     if (c->n_envs <= 0) return DMFB_ERR_BAD_ARG;
-    if (tile_lds_bytes(16, c->n_agents, 3 * c->fov * c->fov + 2, true) > 64 * 1024) return DMFB_ERR_UNSUPPORTED;
+    if (tile_lds_bytes(1, c->n_agents, 3 * c->fov * c->fov + 2, true, table_words(c->fov / 2, band_words(c->fov))) > 64 * 1024)
+        return DMFB_ERR_UNSUPPORTED;
     return DMFB_OK;
 }
 
@@ -260,9 +280,14 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
     dmfb_vec *h = new (std::nothrow) dmfb_vec();
     if (!h) return DMFB_ERR_BAD_ARG;
     h->cfg = *cfg;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && v > 0) h->n_cu = v;
+    }
     DevCfg &d = h->dc;
     d.W = cfg->width; d.L = cfg->length; d.fov = cfg->fov; d.hf = cfg->fov / 2; d.ff = cfg->fov * cfg->fov;
     d.obs_len = 3 * d.ff + 2; d.max_step = 2 * (cfg->width + cfg->length);
+    d.nq = band_words(cfg->fov);
     d.stall = cfg->stall != 0; d.b_degrade = cfg->b_degrade != 0; d.E = cfg->n_envs; d.n = cfg->n_agents;
     d.k0 = (uint32_t)cfg->seed; d.k1 = (uint32_t)(cfg->seed >> 32); d.env_id0 = cfg->env_id0;
     d.per_healthy = 1.0 - cfg->per_degrade;
@@ -304,11 +329,46 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
     h->bytes += sizeof(h->zoom_host);
     CREATE_TRY(hipMemcpyAsync(h->zoom_dev, h->zoom_host, sizeof(h->zoom_host), hipMemcpyHostToDevice, s));
     h->dp.zoom = h->zoom_dev;
+    {   // observation tables (DevPtrs::band): band images [axis][pattern][nq], then the zoom table
+        const int fov = d.fov, hf = d.hf, ff = d.ff, npat = 2 * hf + 1;
+        const size_t words = (size_t)table_words(hf, d.nq);
+        unsigned long long *img = new (std::nothrow) unsigned long long[words]();
+        if (!img) return fail(DMFB_ERR_BAD_ARG);
+        for (int axis = 0; axis < 2; ++axis)
+            for (int pat = 1; pat < npat; ++pat) {
+                unsigned char *bytes = (unsigned char *)(img + ((size_t)axis * npat + pat) * d.nq);
+                for (int b = 0; b < ff; ++b) {
+                    const int v = axis == 0 ? b / fov : b % fov;  // window x (first axis) or y
+                    // pattern p <= hf: the first p window rows/columns lie outside the chip (obs[2, 0:left, :] = 1,
+                    // dmfb.py:430-431); p > hf: the last p - hf ones (obs[2, -right:, :] = 1, dmfb.py:432-433)
+                    if (pat <= hf ? v < pat : v >= fov - (pat - hf)) bytes[b] = 1;
+                }
+            }
+        memcpy(img + (size_t)2 * npat * d.nq, h->zoom_host, sizeof(h->zoom_host));
+        hipError_t e1 = hipMalloc(&h->band_dev, words * 8);
+        if (e1 == hipSuccess) e1 = hipMemcpy(h->band_dev, img, words * 8, hipMemcpyHostToDevice);
+        delete[] img;
+        if (e1 != hipSuccess) { hip_fail(e1, "observation table upload", __LINE__); return fail(DMFB_ERR_HIP); }
+        h->bytes += words * 8;
+        h->dp.band = h->band_dev;
+    }
     CREATE_TRY(hipMemsetAsync(h->dp.st, 0, st_bytes, s));
     d.fov_magic = d.fov >= 2 ? (uint32_t)((0x100000000ull + (uint64_t)d.fov - 1) / (uint64_t)d.fov) : 0u;
     if (const char *v = getenv("DMFB_VEC_MIN_TILE")) h->T_min = atoi(v) > 0 ? atoi(v) : 1;  // tuning knob
     h->T_fused = pick_tile(h, 1024);
     h->T_obs = pick_tile(h, 2048);
+    {   // observation kernel: at most 128 rows per tile, so that the two half-workgroups (layer 0 | layer 1, first | second half
+        // of the band image) each cover every row in one pass
+        int t = 128 / n;
+        t = t < 1 ? 1 : (t > 64 ? 64 : t);
+        while (t > 1 && tile_lds_bytes(t, n, d.obs_len, true, table_words(d.hf, d.nq)) > 64 * 1024) --t;
+        while (t > h->T_min && (E + t - 1) / t < 1024) t = (t + 1) / 2;
+        h->T_obs = t;
+    }
+    if (const char *v = getenv("DMFB_VEC_OBS_TILE")) {  // tuning knob: chips per workgroup of the observation kernel (1..64)
+        const int t = atoi(v);
+        if (t >= 1 && t <= 64 && tile_lds_bytes(t, n, d.obs_len, true, table_words(d.hf, d.nq)) <= 64 * 1024) h->T_obs = t;
+    }
     d.T = h->T_fused; d.T_obs = h->T_obs;
     for (uint32_t k = 0; k < 64u * DMFB_MAX_AGENTS * (uint32_t)d.fov && d.fov >= 2; ++k)  // the magic must be exact on the range used
         if ((uint32_t)(((uint64_t)k * d.fov_magic) >> 32) != k / (uint32_t)d.fov) return fail(DMFB_ERR_UNSUPPORTED);
@@ -327,6 +387,7 @@ int dmfb_vec_destroy(dmfb_vec *h) {
     DeviceGuard g(h->cfg.device);
     (void)hipFree(h->dp.st); (void)hipFree(h->dp.starts); (void)hipFree(h->dp.health);
     (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage); (void)hipFree(h->zoom_dev); (void)hipFree(h->dp.blocks);
+    (void)hipFree(h->band_dev);
     delete h;
     return DMFB_OK;
 }
@@ -458,6 +519,15 @@ int dmfb_vec_zoom_lut(const dmfb_vec *h, int8_t *host_out) {
     memcpy(host_out, h->zoom_host, sizeof(h->zoom_host));
     return DMFB_OK;
 }
+
+#ifdef DMFB_STAMPS
+// diagnostic build only (not declared in include/dmfb_vec.h): attach a device buffer of 8 uint64 per k_observe workgroup
+int dmfb_vec_dbg_stamps(dmfb_vec *h, unsigned long long *d_buf) {
+    if (!h) return DMFB_ERR_BAD_ARG;
+    h->dp.dbg = d_buf;
+    return DMFB_OK;
+}
+#endif
 
 const char *dmfb_vec_strerror(int code) {
     switch (code) {

@@ -29,7 +29,7 @@ template <>
 hipError_t launch_observe_n<DMFB_TU_N>(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int8_t *obs, int grid,
                                        size_t lds, hipStream_t s) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_observe<DMFB_TU_N>), dim3(grid), dim3(kBlock), lds, s, c, p, mask, obs);
+    hipLaunchKernelGGL((k_observe<DMFB_TU_N>), dim3(grid), dim3(kObsBlock), lds, s, c, p, mask, obs);
     return hipGetLastError();
 }
 
