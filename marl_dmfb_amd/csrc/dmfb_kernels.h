@@ -73,14 +73,21 @@ struct DevPtrs {
 // In-kernel time stamps exist only in the diagnostic build (make stamps -> lib/libdmfb_vec_stamps.so, tools/exp_stamps.py);
 // the shipped kernels contain none.
 #ifdef DMFB_STAMPS
+// accumulates, per workgroup, the cycles between consecutive stamps: dbg[wg][k] += now - previous stamp
 #define DMFB_STAMP(k)                                                                               \
     do {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                          \
-        if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+        if (threadIdx.x == 0 && p.dbg) {                                                            \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                           \
+            p.dbg[(size_t)blockIdx.x * 8 + (k)] += now_ - stamp_prev_;                              \
+            stamp_prev_ = now_;                                                                     \
+        }                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     } while (0)
+#define DMFB_STAMP_INIT() unsigned long long stamp_prev_ = __builtin_amdgcn_s_memtime()
 #else
 #define DMFB_STAMP(k) do { } while (0)
+#define DMFB_STAMP_INIT() do { } while (0)
 #endif
 
 // ---- packed record layout -------------------------------------------------------------------
@@ -782,57 +789,57 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
 template <int N>
 __global__ __launch_bounds__(kObsBlock) void k_observe(DevCfg c, DevPtrs p, const uint8_t *mask, int8_t *gobs) {
     // Persistent workgroups: the grid covers the CUs a few times over and every workgroup walks tiles blockIdx.x,
-    // blockIdx.x + gridDim.x, ...  The observation tables are copied into LDS once per workgroup.  The packed records
-    // run two tiles ahead: while tile k is scattered, the records of tile k+1 sit in registers; just before tile k is
-    // streamed out they are unpacked into the second position buffer and the loads for tile k+2 are issued.  The only
-    // wait for global memory (gfx950 counts loads and stores in one in-order counter) therefore falls where the previous
-    // tile's stores have long drained, never between a tile's stores and the next tile's zero fill.
+    // blockIdx.x + gridDim.x, ...  The observation tables are copied into LDS once per workgroup.
+    // Roles: the LAST wave is the loader -- it alone reads global memory (packed records, mask; one chip per lane,
+    // T <= 64) and never stores; the other waves stream the finished tiles out and never load.  gfx950 counts a wave's
+    // loads and stores in ONE in-order counter, so a wave that did both would have to wait for the acknowledgement of
+    // its previous tile's stores before it could use the next records.  With the roles split no wave ever waits for a
+    // store: a tile's LDS is reused as soon as it has been READ.
+    // The records run two tiles ahead: while tile k is scattered the records of tile k+1 sit in the loader's registers;
+    // before tile k is streamed out they are unpacked into the second position buffer and tile k+2 is requested.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = c.T_obs, E = c.E;
     const int tid = threadIdx.x;
+    constexpr int kWork = kObsBlock - kWave;  // threads that stream tiles out
+    const bool loader = tid >= kWork;
+    const int ltid = tid - kWork;
     const int ntiles = (E + T - 1) / T;
     const int row_bytes = N * c.obs_len;
     constexpr int NP = Rec<N>::NP;
-    constexpr int kPre = (64 * NP + kObsBlock - 1) / kObsBlock;  // T <= 64: at most this many (word, chip) items per thread
-    uint32_t pw[kPre], gw[kPre];
-    auto prefetch = [&](int tile) {  // coalesced: consecutive lanes, consecutive chips
-        const int base = tile * T, tvn = min(T, E - base);
+    uint32_t pw[NP], gw[NP];
+    auto prefetch = [&](int tile) {  // lane = chip: for every record word the lanes read consecutive addresses
+        const int base = tile * T;
+        const bool on = tile < ntiles && ltid < min(T, E - base);
 #pragma unroll
-        for (int k = 0; k < kPre; ++k) {
-            const int it = tid + k * kObsBlock;
-            pw[k] = gw[k] = 0;
-            if (tile < ntiles && it < tvn * NP) {
-                const int w = it / tvn, s = it - w * tvn;
-                pw[k] = p.st[(size_t)w * E + base + s];
-                gw[k] = p.st[(size_t)(NP + w) * E + base + s];
-            }
+        for (int w = 0; w < NP; ++w) {
+            pw[w] = on ? p.st[(size_t)w * E + base + ltid] : 0u;
+            gw[w] = on ? p.st[(size_t)(NP + w) * E + base + ltid] : 0u;
         }
     };
     const Tile t0 = carve(smem, T, N, c.obs_len, true, table_words(c.hf, c.nq), 0);
-    // second position/goal buffer behind the tile structure (tile_lds_bytes reserves it for the observation kernel)
+    // second position/goal buffer behind the tile structure (tile_lds_bytes reserves it)
     uint32_t *const pos2 = (uint32_t *)(t0.flag + align16((size_t)T));
     auto unpack = [&](int tile, uint32_t *pos, uint32_t *goal) {
-        const int tvn = tile < ntiles ? min(T, E - tile * T) : 0;
+        if (tile >= ntiles || ltid >= min(T, E - tile * T)) return;
 #pragma unroll
-        for (int k = 0; k < kPre; ++k) {
-            const int it = tid + k * kObsBlock;
-            if (it < tvn * NP) {
-                const int w = it / tvn, s = it - w * tvn;
-                pos[s * N + 2 * w] = to_xy(pw[k]);
-                goal[s * N + 2 * w] = to_xy(gw[k]);
-                if (2 * w + 1 < N) {
-                    pos[s * N + 2 * w + 1] = to_xy(pw[k] >> 16);
-                    goal[s * N + 2 * w + 1] = to_xy(gw[k] >> 16);
-                }
+        for (int w = 0; w < NP; ++w) {
+            pos[ltid * N + 2 * w] = to_xy(pw[w]);
+            goal[ltid * N + 2 * w] = to_xy(gw[w]);
+            if (2 * w + 1 < N) {
+                pos[ltid * N + 2 * w + 1] = to_xy(pw[w] >> 16);
+                goal[ltid * N + 2 * w + 1] = to_xy(gw[w] >> 16);
             }
         }
     };
     int tile = blockIdx.x;
     int buf = 0;
-    prefetch(tile);
-    load_tables(c, p, t0, tid, kObsBlock);
-    unpack(tile, t0.pos, t0.goal);
-    prefetch(tile + gridDim.x);
+    DMFB_STAMP_INIT();
+    if (loader) {
+        prefetch(tile);
+        load_tables(c, p, t0, ltid, kWave);
+        unpack(tile, t0.pos, t0.goal);
+        prefetch(tile + gridDim.x);
+    }
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         const int tile_base = tile * T;
         const int shift = (int)(((uintptr_t)gobs + (size_t)tile_base * row_bytes) & 15);
@@ -841,37 +848,46 @@ __global__ __launch_bounds__(kObsBlock) void k_observe(DevCfg c, DevPtrs p, cons
         if (buf) { t.pos = pos2; t.goal = pos2 + (size_t)T * N; }
         const int tv = min(T, E - tile_base);
         // this barrier publishes the positions unpacked during the previous tile and separates its stream-out (LDS
-        // reads) from the zero fill below
-        const int cnt = __syncthreads_count(tid < tv && (!mask || mask[tile_base + tid] != 0));  // T <= 64 <= kObsBlock
+        // reads) from the zero fill below; the loader's lanes flag and count the chips to refresh
+        bool refresh = false;
+        if (loader && ltid < tv) {
+            refresh = !mask || mask[tile_base + ltid] != 0;
+            t0.flag[ltid] = (uint8_t)refresh;
+        }
+        const int cnt = __syncthreads_count(refresh);
         DMFB_STAMP(0);
         if (cnt != 0) {  // (uniform) something to refresh in this tile
             zero_tile(smem, (int)(align16((size_t)shift + (size_t)tv * row_bytes) >> 4), tid, kObsBlock);
             DMFB_STAMP(1);
             __syncthreads();
             DMFB_STAMP(2);
+#ifndef DMFB_ABLATE_BANDS  // timing experiments only (tools/build_variant.sh with EXTRA_FLAGS): wrong observations
             scatter_bands<N>(c, t, smem, tv, tid, kObsBlock);
             __syncthreads();
+#endif
             DMFB_STAMP(3);
+#ifndef DMFB_ABLATE_ROWS
             scatter_rows<N>(c, p, t, tile_base, tv, tid, kObsBlock);
             __syncthreads();
+#endif
             DMFB_STAMP(4);
         }
-        unpack(tile + gridDim.x, npos, ngoal);
-        prefetch(tile + 2 * gridDim.x);
-        DMFB_STAMP(5);
-        if (cnt == tv) {
-            copy_tile_out(t, shift, gobs, (size_t)tile_base * row_bytes, tv * row_bytes, tid, kObsBlock);
+        if (loader) {
+            unpack(tile + gridDim.x, npos, ngoal);
+            prefetch(tile + 2 * gridDim.x);
+        } else if (cnt == tv) {
+            copy_tile_out(t, shift, gobs, (size_t)tile_base * row_bytes, tv * row_bytes, tid, kWork);
         } else if (cnt != 0) {
             for (int s = 0; s < tv; ++s)
-                if (mask[tile_base + s])
-                    for (int b = tid; b < row_bytes; b += kObsBlock)
+                if (t0.flag[s])
+                    for (int b = tid; b < row_bytes; b += kWork)
                         gobs[(size_t)(tile_base + s) * row_bytes + b] = t.obs[(size_t)s * row_bytes + b];
         }
-        DMFB_STAMP(6);
+        DMFB_STAMP(5);
     }
 #ifdef DMFB_STAMPS
     __builtin_amdgcn_s_waitcnt(0);  // stores acknowledged
-    DMFB_STAMP(7);
+    DMFB_STAMP(6);
 #endif
 }
 

@@ -18,7 +18,7 @@ from marl_dmfb_amd.env.dmfb import VecDMFB  # noqa: E402
 
 CFGS = {'A': dict(width=10, length=10, n_agents=4, fov=9), 'D': dict(width=50, length=50, n_agents=10, fov=9),
         'E': dict(width=20, length=20, n_agents=10, fov=9)}
-NAMES = ['zero_fill', 'barrier', 'bands+bar', 'rows+bar', 'unpack_next+prefetch', 'copy_issue', 'to_kernel_end']  # last tile of each persistent workgroup
+NAMES = ['top_barrier', 'zero_fill', 'barrier', 'bands+bar', 'rows+bar', 'copy_issue(|loader)', 'final_drain']  # cycles summed over a workgroup's tiles
 
 if __name__ == '__main__':
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
@@ -34,14 +34,14 @@ if __name__ == '__main__':
         for _ in range(3):
             env.observe()
         torch.cuda.synchronize()
+        buf.zero_()
+        env.observe()
+        torch.cuda.synchronize()
         st = buf.cpu().numpy().astype(np.int64)
-        st = st[st[:, 0] != 0]  # the persistent grid has fewer workgroups than tiles
-        d = np.diff(st, axis=1)
-        life = st[:, 7] - st[:, 0]
-        span = st[:, 7].max() - st[:, 0].min()
-        out = {'cfg': name, 'E': E, 'tile': T, 'workgroups': int(st.shape[0]), 'kernel_span_cycles': int(span),
-               'median_cycles': {n: int(np.median(d[:, k])) for k, n in enumerate(NAMES)},
-               'p90_cycles': {n: int(np.percentile(d[:, k], 90)) for k, n in enumerate(NAMES)},
-               'median_lifetime': int(np.median(life)), 'avg_resident_per_cu': round(float(life.sum()) / float(span) / 256, 2)}
+        st = st[st.sum(axis=1) != 0]  # the persistent grid has fewer workgroups than tiles
+        tiles_per_wg = wgs / st.shape[0]
+        out = {'cfg': name, 'E': E, 'tile': T, 'workgroups': int(st.shape[0]), 'tiles_per_wg': round(tiles_per_wg, 2),
+               'median_cycles_per_tile': {n: int(np.median(st[:, k]) / tiles_per_wg) for k, n in enumerate(NAMES)},
+               'total_per_tile': int(np.median(st[:, :7].sum(axis=1)) / tiles_per_wg)}
         print(json.dumps(out), flush=True)
         env.close()
