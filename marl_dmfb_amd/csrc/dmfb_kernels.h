@@ -49,6 +49,8 @@ struct DevCfg {
     uint32_t k0, k1, env_id0;
     uint32_t fov_magic;  // ceil(2^32 / fov): k / fov == __umulhi(k, fov_magic) for the ranges used (fov >= 2)
     int nq;              // 8-byte words per band image, padded to a multiple of 12 (see DevPtrs::band)
+    int ucap;            // steps a chip's usage log holds (= max_step), see DevPtrs::ulog
+    int hist_bytes;      // LDS bytes of one wave's usage histogram, 0 = chip too large for LDS (global-atomic path)
     double per_healthy;
 };
 
@@ -58,6 +60,11 @@ struct DevPtrs {
     double *health;    // [E][W*L] or nullptr
     double *degrade;   // [E][W*L]
     uint16_t *usage;   // [E][W*L]
+    // addUsage (dmfb.py:459-463) as an append-only log: step k of a chip since its last flush stores, per droplet, the cell
+    // index x*L+y it occupies (0xFFFF: the droplet is on its goal) at ulog[(e*ucap + k)*n + i].  A transition writes 2n
+    // contiguous bytes instead of n read-modify-writes scattered over a 64/128-byte sector each; the log is folded into the
+    // usage map (flush_usage) when the episode is reset, when it is full, and before the map is read or written from outside.
+    uint16_t *ulog;
     const int8_t *zoom;  // [2][511] direction zoom table
     uint32_t *blocks;    // [n_blocks][E] x_min | x_max<<8 | y_min<<16 | y_max<<24, or nullptr
     // Observation tables, copied into LDS by every workgroup that builds observations (table_words() 8-byte words):
@@ -92,13 +99,15 @@ struct DevPtrs {
 
 // ---- packed record layout -------------------------------------------------------------------
 // NP = ceil(N/2) words of positions (agent i: word i>>1, half i&1, value x | y<<8),
-// NP words of goals, then: step_count | flags<<16, cumulative constraints, rng_step, rng_ep, rng_map.
+// NP words of goals, then: step_count | flags<<16 | usage-log length<<20, cumulative constraints, rng_step, rng_ep, rng_map.
 template <int N> struct Rec {
     static constexpr int NP = (N + 1) / 2;
     static constexpr int W_POS = 0, W_GOAL = NP, W_STEP = 2 * NP, W_CUM = 2 * NP + 1,
                          W_RSTEP = 2 * NP + 2, W_REP = 2 * NP + 3, W_RMAP = 2 * NP + 4, NW = 2 * NP + 5;
 };
 constexpr uint32_t FLAG_DUP = 1u;  // two droplets share a cell (only reachable through set_task)
+constexpr uint32_t kFlagMask = 0xfu;   // bits 16..19 of the step word
+constexpr int kUlenShift = 20;         // bits 20..31: steps in the chip's usage log (<= max_step <= 1020)
 
 __host__ __device__ inline int rec_words(int n) { return 2 * ((n + 1) / 2) + 5; }
 __host__ __device__ inline int table_words(int hf, int nq) { return 2 * (2 * hf + 1) * nq + 128; }
@@ -128,7 +137,7 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1
 // ---- per-lane env registers -------------------------------------------------------------------
 template <int N> struct EnvR {
     int x[N], y[N], gx[N], gy[N];
-    uint32_t step, flags, cum, rstep, rep, rmap;
+    uint32_t step, flags, ulen, cum, rstep, rep, rmap;
 };
 
 template <int N>
@@ -146,7 +155,7 @@ __device__ __forceinline__ void load_env(const DevPtrs &p, int E, int e, EnvR<N>
         }
     }
     uint32_t s = p.st[(size_t)R::W_STEP * E + e];
-    r.step = s & 0xffff; r.flags = s >> 16;
+    r.step = s & 0xffff; r.flags = (s >> 16) & kFlagMask; r.ulen = s >> kUlenShift;
     r.cum = p.st[(size_t)R::W_CUM * E + e];
     r.rstep = p.st[(size_t)R::W_RSTEP * E + e];
     r.rep = p.st[(size_t)R::W_REP * E + e];
@@ -167,7 +176,7 @@ __device__ __forceinline__ void store_env(const DevPtrs &p, int E, int e, const 
         p.st[(size_t)(R::W_POS + w) * E + e] = pack_pos<N>(r.x, r.y, w);
         if (with_goal) p.st[(size_t)(R::W_GOAL + w) * E + e] = pack_pos<N>(r.gx, r.gy, w);
     }
-    p.st[(size_t)R::W_STEP * E + e] = (r.step & 0xffff) | (r.flags << 16);
+    p.st[(size_t)R::W_STEP * E + e] = (r.step & 0xffff) | (r.flags << 16) | (r.ulen << kUlenShift);
     p.st[(size_t)R::W_CUM * E + e] = r.cum;
     p.st[(size_t)R::W_RSTEP * E + e] = r.rstep;
     p.st[(size_t)R::W_REP * E + e] = r.rep;
@@ -309,6 +318,56 @@ __device__ __forceinline__ void gen_degrade_env(const DevCfg &c, const DevPtrs &
     }
 }
 
+// Fold a chip's usage log into its usage map and, if `update`, run updateHealth (dmfb.py:465-471) on the result.
+// Executed by ONE wave; `hist` = c.hist_bytes of LDS owned by the wave (nullptr when the chip is too large: the counts
+// then go straight to the map with 32-bit global atomics on the containing words).  Global traffic: the log read once,
+// the map read and written once, both contiguous.
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+__device__ __forceinline__ void flush_usage(const DevCfg &c, const DevPtrs &p, int e, int ulen, bool update, uint16_t *hist, int lane) {
+    const int cells = c.W * c.L;
+    const size_t base = (size_t)e * cells;
+    const uint16_t *log = p.ulog + (size_t)e * c.ucap * c.n;
+    const int entries = ulen * c.n;
+    if (hist) {
+        uint32_t *h32 = (uint32_t *)hist;
+        for (int k = lane; k < cells; k += kWave) hist[k] = p.usage[base + k];
+        wave_fence();
+        for (int k = lane; k < entries; k += kWave) {
+            const uint32_t cell = log[k];
+            if (cell != 0xffffu) atomicAdd(&h32[cell >> 1], 1u << (16 * (cell & 1)));
+        }
+        wave_fence();
+        for (int k = lane; k < cells; k += kWave) {
+            uint16_t u = hist[k];
+            if (update && u > 50) {
+                p.health[base + k] = p.health[base + k] * p.degrade[base + k];
+                u = 0;
+            }
+            p.usage[base + k] = u;
+        }
+        wave_fence();
+        return;
+    }
+    uint32_t *u32 = (uint32_t *)p.usage;  // hipMalloc'ed: 4-byte aligned
+    for (int k = lane; k < entries; k += kWave) {
+        const uint32_t cell = log[k];
+        if (cell != 0xffffu) {
+            const size_t g = base + cell;
+            atomicAdd(&u32[g >> 1], 1u << (16 * (g & 1)));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    if (!update) return;
+    for (int k = lane; k < cells; k += kWave) {
+        const size_t g = base + k;
+        const uint32_t w = __hip_atomic_load(&u32[g >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not through this CU's L1
+        if (((w >> (16 * (g & 1))) & 0xffffu) > 50) {
+            p.health[g] = p.health[g] * p.degrade[g];
+            atomicAnd(&u32[g >> 1], (g & 1) ? 0x0000ffffu : 0xffff0000u);  // the neighbouring cell may belong to another lane
+        }
+    }
+}
+
 // ---- LDS tile -----------------------------------------------------------------------------------
 struct Tile {
     int8_t *obs;       // [T][N][obs_len], 16-byte aligned (absent in the step-only launch)
@@ -316,6 +375,7 @@ struct Tile {
     uint32_t *goal;    // [T][N]
     uint8_t *flag;     // [T] per-env flag (ended / masked)
     unsigned long long *tab;  // LDS copy of DevPtrs::band (band images, then the zoom table)
+    uint16_t *ulen;           // [T] usage-log length of the chips whose log must be folded in after the step
 };
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 // LDS bytes of a workgroup: obs block (0 for the step-only launch) + pos/goal + flags
@@ -324,7 +384,7 @@ __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t
 __host__ __device__ inline size_t tile_lds_bytes(int T, int n, int obs_len, bool with_obs, int tab_words) {
     // observation tile + tables, positions/goals, flags, and (observation kernel) a second positions/goals buffer
     return (with_obs ? align16((size_t)T * n * obs_len + 16) + (size_t)tab_words * 8 + (size_t)T * n * 8 : 0) + (size_t)T * n * 8 +
-           align16((size_t)T);
+           align16((size_t)T) + align16((size_t)2 * T);
 }
 __device__ __forceinline__ Tile carve(unsigned char *smem, int T, int n, int obs_len, bool with_obs, int tab_words, int shift = 0) {
     Tile t;
@@ -335,6 +395,7 @@ __device__ __forceinline__ Tile carve(unsigned char *smem, int T, int n, int obs
     t.pos = (uint32_t *)(smem + off);
     t.goal = t.pos + (size_t)T * n;
     t.flag = (uint8_t *)(t.goal + (size_t)T * n);
+    t.ulen = (uint16_t *)(t.flag + align16((size_t)T) + (with_obs ? (size_t)T * n * 8 : 0));
     return t;
 }
 // copy the observation tables into LDS (any subset of the workgroup's threads; a barrier follows before they are read)
@@ -539,6 +600,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
         const bool active = present && (!a.active || a.active[e]);
         EnvR<N> r;
         bool ended = false;
+        int flush_len = 0, flush_kind = 0;
         if (present) load_env<N>(p, E, e, r);
         if (present && !active) {  // episode over, not reset yet: report a finished env, touch nothing
 #pragma unroll
@@ -677,20 +739,14 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
                 }
                 rew[i] = v;
             }
-            if (MAPS && (a.flags & DMFB_STEP_RECORD)) {  // addUsage (dmfb.py:459-463)
-                uint16_t *um = p.usage + (size_t)e * cells;
-                if (!dup) {  // droplets sit on distinct cells: all loads in flight together, then all stores
-                    uint16_t uv[N];
+            bool log_full = false;
+            if (MAPS && (a.flags & DMFB_STEP_RECORD)) {  // addUsage (dmfb.py:459-463): append this step to the chip's usage log
+                uint16_t *ul = p.ulog + ((size_t)e * c.ucap + r.ulen) * N;
 #pragma unroll
-                    for (int i = 0; i < N; ++i) uv[i] = um[r.x[i] * c.L + r.y[i]];
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        if ((iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) != 0) um[r.x[i] * c.L + r.y[i]] = (uint16_t)(uv[i] + 1);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        if ((iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) != 0) um[r.x[i] * c.L + r.y[i]] += 1;
-                }
+                for (int i = 0; i < N; ++i)
+                    ul[i] = (iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) != 0 ? (uint16_t)(r.x[i] * c.L + r.y[i]) : (uint16_t)0xffff;
+                r.ulen += 1;
+                log_full = (int)r.ulen == c.ucap;  // folded into the map right after this step: a step always finds room
             }
             r.cum += (uint32_t)constraints;
             const bool in_time = (int)r.step < c.max_step;  // DMFBenv.step (dmfb.py:577-585)
@@ -729,6 +785,11 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
             }
             if (dup) r.flags = any_dup<N>(r) ? (r.flags | FLAG_DUP) : (r.flags & ~FLAG_DUP);
             ended = term && (a.flags & DMFB_STEP_AUTORESET);
+            if (MAPS && (ended || log_full)) {  // the waves fold the log in after the barrier (flush_usage)
+                flush_len = (int)r.ulen;
+                flush_kind = ended ? 1 : 2;  // 1: + updateHealth (reset(new=False), dmfb.py:182-183)   2: log full
+                r.ulen = 0;
+            }
         }
         // ---- episode boundary inside the launch: reset(new=False) for the lanes that ended
         unsigned long long m = __ballot(ended);
@@ -759,20 +820,26 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
                     t.goal[slot * N + i] = (uint32_t)r.gx[i] | ((uint32_t)r.gy[i] << 16);
                 }
             }
-            t.flag[slot] = (uint8_t)ended;
+            t.flag[slot] = (uint8_t)flush_kind;
+            if (MAPS) t.ulen[slot] = (uint16_t)flush_len;
         }
     }
-    if (!want_obs && !(MAPS && (a.flags & DMFB_STEP_AUTORESET))) return;
+    const bool may_flush = MAPS && (a.flags & (DMFB_STEP_AUTORESET | DMFB_STEP_RECORD));
+    if (!want_obs && !may_flush) return;
     __syncthreads();
-    if (MAPS && (a.flags & DMFB_STEP_AUTORESET)) {  // updateHealth for the envs that were reset (dmfb.py:182-183)
-        // one flag read per thread + a wave ballot instead of a serial scan of the tile's flags
+    if (may_flush) {  // usage logs of the chips that were reset (+ updateHealth) or whose log is full
+        // one flag read per thread + a wave ballot instead of a serial scan of the tile's flags; every wave folds the
+        // chips of its own 64 slots through its own LDS histogram
+        uint16_t *hist = c.hist_bytes ? (uint16_t *)(smem + tile_lds_bytes(T, N, c.obs_len, want_obs, table_words(c.hf, c.nq)) +
+                                                     (size_t)wave * c.hist_bytes) : nullptr;
         for (int base = 0; base < tv; base += kBlock) {
             const int s = base + tid;
             unsigned long long fm = __ballot(s < tv && t.flag[s] != 0);
             while (fm) {
                 const int src = __ffsll((long long)fm) - 1;
                 fm &= fm - 1;
-                update_health_env(p, cells, tile_base + base + wave * kWave + src, lane, kWave);
+                const int slot = base + wave * kWave + src;
+                flush_usage(c, p, tile_base + slot, t.ulen[slot], t.flag[slot] == 1, hist, lane);
             }
         }
     }
@@ -916,11 +983,14 @@ __global__ __launch_bounds__(kBlock) void k_reset(DevCfg c, DevPtrs p, const uin
 #pragma unroll
                 for (int j = i + 1; j < N; ++j)
                     d |= ((sw[i >> 1] >> (16 * (i & 1))) & 0xffff) == ((sw[j >> 1] >> (16 * (j & 1))) & 0xffff);
-            p.st[(size_t)R::W_STEP * E + e] = d ? (FLAG_DUP << 16) : 0u;
+            // counters to zero, the usage log keeps its length (restart does not touch the maps)
+            p.st[(size_t)R::W_STEP * E + e] = (p.st[(size_t)R::W_STEP * E + e] & (0xfffu << kUlenShift)) | (d ? (FLAG_DUP << 16) : 0u);
             p.st[(size_t)R::W_CUM * E + e] = 0;
         }
         return;
     }
+    // steps waiting in the usage log (read by every lane before lane 0 rewrites the record)
+    const int ulen = (mode == 3 || !p.health) ? 0 : (int)(p.st[(size_t)R::W_STEP * E + e] >> kUlenShift);
     uint32_t rep = mode == 3 ? 0u : p.st[(size_t)R::W_REP * E + e];
     uint32_t rmap = mode == 3 ? 0u : p.st[(size_t)R::W_RMAP * E + e];
     uint32_t pts[N];
@@ -934,16 +1004,18 @@ __global__ __launch_bounds__(kBlock) void k_reset(DevCfg c, DevPtrs p, const uin
         int sx[N], sy[N];
         task_to_env<N>(pts, r, sx, sy);
         store_starts<N>(p, E, e, sx, sy);
-        r.step = 0; r.flags = 0; r.cum = 0;
+        r.step = 0; r.flags = 0; r.cum = 0; r.ulen = 0;
         r.rstep = mode == 3 ? 0u : p.st[(size_t)R::W_RSTEP * E + e];
         r.rep = rep + 1;
         r.rmap = rmap + ((mode == 1 || mode == 3) && p.health && c.b_degrade ? 1u : 0u);
         store_env<N>(p, E, e, r, true);
     }
     if (p.health) {
-        if (mode == 0) {
-            update_health_env(p, cells, e, lane, kWave);
-        } else {
+        if (mode == 0) {  // refresh(new=False): the episode's usage, then updateHealth (dmfb.py:182-183)
+            extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+            uint16_t *hist = c.hist_bytes ? (uint16_t *)(smem + (size_t)(threadIdx.x / kWave) * c.hist_bytes) : nullptr;
+            flush_usage(c, p, e, ulen, true, hist, lane);
+        } else {  // new maps: whatever the log holds is discarded with the old usage map
             const size_t base = (size_t)e * cells;
             for (int cidx = lane; cidx < cells; cidx += kWave) { p.health[base + cidx] = 1.0; p.usage[base + cidx] = 0; }
             gen_degrade_env(c, p, cells, e, rmap, lane, kWave);
@@ -956,7 +1028,7 @@ __global__ __launch_bounds__(kBlock) void k_reset(DevCfg c, DevPtrs p, const uin
 template <int N>
 hipError_t launch_step_n(const DevCfg &c, const DevPtrs &p, const StepArgs &a, int grid, size_t lds, hipStream_t s);
 template <int N>
-hipError_t launch_reset_n(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int mode, int grid, hipStream_t s);
+hipError_t launch_reset_n(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int mode, int grid, size_t lds, hipStream_t s);
 template <int N>
 hipError_t launch_observe_n(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int8_t *obs, int grid, size_t lds,
                             hipStream_t s);

@@ -38,8 +38,25 @@ __global__ void k_set_task(DevCfg c, DevPtrs p, const int32_t *starts, const int
             const size_t a = ((size_t)e * n + i) * 2, b = ((size_t)e * n + j) * 2;
             dup |= (starts[a] == starts[b]) && (starts[a + 1] == starts[b + 1]);
         }
-    p.st[(size_t)(2 * np) * E + e] = dup ? (FLAG_DUP << 16) : 0u;
+    // counters to zero; the usage log keeps its length (injecting a task does not touch the maps)
+    p.st[(size_t)(2 * np) * E + e] = (p.st[(size_t)(2 * np) * E + e] & (0xfffu << kUlenShift)) | (dup ? (FLAG_DUP << 16) : 0u);
     p.st[(size_t)(2 * np + 1) * E + e] = 0;
+}
+
+// Fold every chip's usage log into its usage map (no updateHealth): before the map is read or overwritten from outside.
+// One wave per chip, LDS histogram per wave (dynamic LDS = 4 * hist_bytes).
+__global__ __launch_bounds__(kBlock) void k_flush_usage(DevCfg c, DevPtrs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int e = blockIdx.x * (kBlock / kWave) + (int)(threadIdx.x / kWave);
+    if (e >= c.E) return;
+    const int lane = (int)(threadIdx.x & (kWave - 1));
+    const size_t wstep = (size_t)(2 * ((c.n + 1) / 2)) * c.E + e;
+    const uint32_t s = p.st[wstep];
+    const int ulen = (int)(s >> kUlenShift);
+    if (ulen == 0) return;  // (wave-uniform)
+    uint16_t *hist = c.hist_bytes ? (uint16_t *)(smem + (size_t)(threadIdx.x / kWave) * c.hist_bytes) : nullptr;
+    flush_usage(c, p, e, ulen, false, hist, lane);
+    if (lane == 0) p.st[wstep] = s & ~(0xfffu << kUlenShift);
 }
 
 __global__ void k_get_task(DevCfg c, DevPtrs p, int32_t *starts, int32_t *ends) {
@@ -161,6 +178,12 @@ struct dmfb_vec {
 
 namespace {
 
+// LDS of the usage histograms (one per wave) of a kernel that may fold usage logs into the maps
+size_t hist_lds(const dmfb_vec *h) { return h->dp.health ? (size_t)(kBlock / kWave) * h->dc.hist_bytes : 0; }
+
+// chips up to this many cells count a usage log through an LDS histogram; larger ones use global atomics
+constexpr int kHistMaxCells = 4096;
+
 // 8-byte words per band image: the fov*fov layer bytes, padded so that the kernel reads them in batches of 12
 int band_words(int fov) { return ((fov * fov + 7) / 8 + 11) / 12 * 12; }
 
@@ -172,12 +195,13 @@ int pick_tile(const dmfb_vec *h, int min_groups) {
     int T = 64;
     size_t cap = 40 * 1024;
     if (const char *v = getenv("DMFB_VEC_TILE_KB")) cap = (size_t)atoi(v) * 1024;  // tuning knob
-    while (T > 1 && ((size_t)T * row > cap || tile_lds_bytes(T, h->cfg.n_agents, h->dc.obs_len, true, table_words(h->dc.hf, h->dc.nq)) > 64 * 1024)) T >>= 1;
+    while (T > 1 && ((size_t)T * row > cap || tile_lds_bytes(T, h->cfg.n_agents, h->dc.obs_len, true, table_words(h->dc.hf, h->dc.nq)) + hist_lds(h) > 64 * 1024)) T >>= 1;
     while (T > h->T_min && (h->cfg.n_envs + T - 1) / T < min_groups) T >>= 1;
     return T;
 }
 
 constexpr int kStepOnlyTile = 256;  // step-only launch: every wave of the workgroup owns 64 chips
+
 
 template <int N> int observe_n(const dmfb_vec *h, const uint8_t *mask, int8_t *obs, hipStream_t s) {
     const int T = h->T_obs;
@@ -200,17 +224,19 @@ template <int N> int step_n(dmfb_vec *h, const StepArgs &a, hipStream_t s) {
         b.out.d_obs = nullptr;
         DevCfg c = h->dc;
         c.T = kStepOnlyTile;
-        HIP_TRY(launch_step_n<N>(c, h->dp, b, (E + c.T - 1) / c.T, tile_lds_bytes(c.T, N, c.obs_len, false, 0), s));
+        HIP_TRY(launch_step_n<N>(c, h->dp, b, (E + c.T - 1) / c.T, tile_lds_bytes(c.T, N, c.obs_len, false, 0) + hist_lds(h), s));
         return observe_n<N>(h, nullptr, a.out.d_obs, s);
     }
     DevCfg c = h->dc;
     const bool with_obs = a.out.d_obs != nullptr;
     c.T = with_obs ? h->T_fused : kStepOnlyTile;
-    HIP_TRY(launch_step_n<N>(c, h->dp, a, (E + c.T - 1) / c.T, tile_lds_bytes(c.T, N, c.obs_len, with_obs, table_words(c.hf, c.nq)), s));
+    HIP_TRY(launch_step_n<N>(c, h->dp, a, (E + c.T - 1) / c.T,
+                             tile_lds_bytes(c.T, N, c.obs_len, with_obs, table_words(c.hf, c.nq)) + hist_lds(h), s));
     return DMFB_OK;
 }
 template <int N> int reset_n(dmfb_vec *h, const uint8_t *mask, int mode, hipStream_t s) {
-    HIP_TRY(launch_reset_n<N>(h->dc, h->dp, mask, mode, (h->cfg.n_envs + (kBlock / kWave) - 1) / (kBlock / kWave), s));
+    HIP_TRY(launch_reset_n<N>(h->dc, h->dp, mask, mode, (h->cfg.n_envs + (kBlock / kWave) - 1) / (kBlock / kWave),
+                              (size_t)(kBlock / kWave) * h->dc.hist_bytes, s));
     return DMFB_OK;
 }
 
@@ -308,8 +334,11 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
     if (cfg->b_degrade || cfg->with_maps) {
         CREATE_TRY(hipMalloc(&h->dp.health, cells * E * 8));
         CREATE_TRY(hipMalloc(&h->dp.degrade, cells * E * 8));
-        CREATE_TRY(hipMalloc(&h->dp.usage, cells * E * 2));
-        h->bytes += cells * E * 18;
+        CREATE_TRY(hipMalloc(&h->dp.usage, cells * E * 2 + 4));  // + 4: the 32-bit atomics of the large-chip path stay in bounds
+        d.ucap = d.max_step;
+        CREATE_TRY(hipMalloc(&h->dp.ulog, (size_t)E * d.ucap * n * 2));
+        d.hist_bytes = (int)cells <= kHistMaxCells ? (int)((cells * 2 + 15) & ~(size_t)15) : 0;
+        h->bytes += cells * E * 18 + (size_t)E * d.ucap * n * 2;
     }
     // GenRandomBlocks guards (dmfb.py:230-234): no blocks on tiny chips or above 20 % coverage
     d.nb = cfg->n_blocks;
@@ -386,7 +415,7 @@ int dmfb_vec_destroy(dmfb_vec *h) {
     if (!h) return DMFB_OK;
     DeviceGuard g(h->cfg.device);
     (void)hipFree(h->dp.st); (void)hipFree(h->dp.starts); (void)hipFree(h->dp.health);
-    (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage); (void)hipFree(h->zoom_dev); (void)hipFree(h->dp.blocks);
+    (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage); (void)hipFree(h->dp.ulog); (void)hipFree(h->zoom_dev); (void)hipFree(h->dp.blocks);
     (void)hipFree(h->band_dev);
     delete h;
     return DMFB_OK;
@@ -490,6 +519,11 @@ int dmfb_vec_get_map(const dmfb_vec *h, int which, double *d_buf, void *stream) 
     DeviceGuard g(h->cfg.device);
     const size_t total = (size_t)h->cfg.n_envs * h->cfg.width * h->cfg.length;
     (void)hipGetLastError();  // drop stale errors left by other users of the runtime
+    if (which == DMFB_MAP_USAGE) {  // the steps since the last reset are still in the usage log
+        hipLaunchKernelGGL(k_flush_usage, dim3((h->cfg.n_envs + (kBlock / kWave) - 1) / (kBlock / kWave)), dim3(kBlock), hist_lds(h),
+                           (hipStream_t)stream, h->dc, h->dp);
+        HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_get_map, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
                        h->dp.health, h->dp.degrade, h->dp.usage, which, d_buf);
     HIP_TRY(hipGetLastError());
@@ -502,6 +536,11 @@ int dmfb_vec_set_map(dmfb_vec *h, int which, const double *d_buf, void *stream) 
     DeviceGuard g(h->cfg.device);
     const size_t total = (size_t)h->cfg.n_envs * h->cfg.width * h->cfg.length;
     (void)hipGetLastError();  // drop stale errors left by other users of the runtime
+    if (which == DMFB_MAP_USAGE) {  // pending log entries belong to the map that is being replaced: fold them in first
+        hipLaunchKernelGGL(k_flush_usage, dim3((h->cfg.n_envs + (kBlock / kWave) - 1) / (kBlock / kWave)), dim3(kBlock), hist_lds(h),
+                           (hipStream_t)stream, h->dc, h->dp);
+        HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_set_map, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
                        h->dp.health, h->dp.degrade, h->dp.usage, which, d_buf);
     HIP_TRY(hipGetLastError());

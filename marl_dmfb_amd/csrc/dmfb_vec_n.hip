@@ -19,9 +19,9 @@ hipError_t launch_step_n<DMFB_TU_N>(const DevCfg &c, const DevPtrs &p, const Ste
 
 template <>
 hipError_t launch_reset_n<DMFB_TU_N>(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int mode, int grid,
-                                     hipStream_t s) {
+                                     size_t lds, hipStream_t s) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_reset<DMFB_TU_N>), dim3(grid), dim3(kBlock), 0, s, c, p, mask, mode);
+    hipLaunchKernelGGL((k_reset<DMFB_TU_N>), dim3(grid), dim3(kBlock), lds, s, c, p, mask, mode);
     return hipGetLastError();
 }
 
