@@ -29,6 +29,7 @@ class Evaluator:
         self.generator = None
         self.sync_every = 4  # lock-steps between host checks for "every chip has terminated"
         self.reset_fn = None  # tests replace env.reset() (e.g. by restart() on an injected task)
+        self.uniforms_fn = None  # tests inject the move draws: uniforms_fn(t) -> float64 [E, n] for lock-step t (else Philox)
         # HIP-graph mode: the whole lock-step episode (reset, T x [Q-net, epsilon-greedy, fused env
         # transition, book-keeping]) is captured once and replayed, which removes the per-op host
         # launch cost that otherwise dominates a lock-step of a few thousand chips.
@@ -149,7 +150,8 @@ class Evaluator:
             if rc != 0:
                 raise RuntimeError('rollout action selection failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
             # frozen chips are not stepped: the kernel reports reward 0 / constraints 0 / success 0 / terminated 1
-            obs, _, _, info = self.env.step(actions, active=alive, record=True)
+            u = self.uniforms_fn(t) if self.uniforms_fn is not None else None
+            obs, _, _, info = self.env.step(actions, uniforms=u, active=alive, record=True)
             cons = info['constraints']
             rc = lib.rollout_post_step(E, T, t, vp(alive.data_ptr()), vp(info['terminated'].data_ptr()),
                                        vp(info['team_reward'].data_ptr()), vp(cons.data_ptr()), int(cons.dtype == torch.float64),

@@ -33,3 +33,47 @@ def test_degrade_sweep_layout_and_ageing(tmp_path):
     assert np.all((deg >= 0.6) & (deg < 1.0))                  # per_degrade=1.0: every cell in [0.6, 1) (dmfb.py:159-163)
     path = save_results(args, rewards, steps, success, health, root=str(tmp_path))
     assert np.load(path + '/health.npy').shape == (E, 4, W, W)
+
+
+def test_degrade_sweep_replays_reference_harness():
+    """The reference's Degre_evaluator.evaluate_process (evaDegre.py:8-26) + Evaluator.evaluate (common/rollout.py:69-85)
+    on one ageing chip, captured with injected tasks and move draws (tools/oracle/gen_degre_golden.py), replayed through
+    the vectorised harness: per-epoch health snapshots, steps and success bit-exact, rewards to float64 rounding."""
+    import os
+    from marl_dmfb_amd.agent.agent import Agents
+    from marl_dmfb_amd.common.arguments import make_args
+    from marl_dmfb_amd.env.dmfb import VecDMFB
+    from marl_dmfb_amd.evaDegre import Degre_evaluator
+    from vdn_helpers import det_init
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'degre_harness_10x10_4d.npz'))
+    W, L, n, fov, epochs, tasks = [int(v) for v in g['cfg']]
+    assert float(g['min_gap']) > 1e-3          # the greedy choices are not decided by float rounding
+    env = VecDMFB(W, L, n, fov=fov, stall=True, b_degrade=True, per_degrade=1.0, n_envs=1, seed=9)
+    env.set_map('degrade', g['degrade'][None])
+    env.set_map('usage', g['usage0'][None])
+    args = make_args(drop_num=n, width=W, length=L, fov=fov, device='cuda:0', evaluate_epoch=epochs, evaluate_task=tasks,
+                     **env.get_env_info())
+    agents = Agents(args)
+    det_init(agents.policy.eval_rnn, salt=0.25)
+    ev = Degre_evaluator(env, agents, args)
+    ev.sync_every = 1
+    episode = {'k': -1}
+
+    def reset_fn():          # env.reset() of the reference = refresh(new=False): updateHealth + the (injected) new task
+        episode['k'] += 1
+        env.reset()
+        env.set_task(g['starts'][episode['k']][None], g['ends'][episode['k']][None])
+        return env.observe()
+
+    def uniforms_fn(t):
+        u = g['uniforms'][episode['k'], t]
+        return torch.as_tensor(np.where(np.isnan(u), 2.0, u)[None], dtype=torch.float64, device='cuda:0')
+    ev.reset_fn, ev.uniforms_fn = reset_fn, uniforms_fn
+    rewards, steps, success, health = ev.evaluate_process()
+    assert episode['k'] == epochs * tasks - 1
+    np.testing.assert_array_equal(health[0].view(np.int64), g['health'].view(np.int64))       # bit-exact float64 maps
+    np.testing.assert_array_equal(steps[0], g['steps'])
+    np.testing.assert_array_equal(success[0], g['success'])
+    np.testing.assert_allclose(rewards[0], g['rewards'], rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(env.get_map('health')[0].cpu().numpy().view(np.int64), g['health_end'].view(np.int64))
+    np.testing.assert_array_equal(env.get_map('usage')[0].cpu().numpy(), g['usage_end'])

@@ -248,3 +248,52 @@ def test_reset_new_and_masked_restart():
     np.testing.assert_array_equal(O.observe(), V.observe())
     starts, _ = V.get_task()
     np.testing.assert_array_equal(sv['pos'][mask == 1], starts[mask == 1])
+
+
+def _usage_log_walk(cfg, E, steps, seed, restart_every, check_every, set_usage_at=None, reset_every=None):
+    """addUsage goes through a per-chip log on the GPU (include/dmfb_vec.h): the maps must agree with the
+    oracle's at every point where they are read, also when the log fills up (restart() loops never reset it), when the
+    usage map is read or replaced in the middle of an episode, and across reset(new=False) (updateHealth)."""
+    O = DmfbOracle(n_envs=E, seed=seed, **cfg)
+    V = _vec(n_envs=E, seed=seed, **cfg)
+    rng = np.random.default_rng(seed)
+    n = cfg['n_agents']
+    u0 = rng.integers(30, 50, (E, cfg['width'], cfg['length'])).astype(np.float64)
+    for B in (O, V):
+        B.set_map('usage', u0)
+    for t in range(steps):
+        a = rng.integers(0, 5, (E, n)).astype(np.int32)
+        ro, do, co, so = O.step(a)
+        rv, dv, cv, sv = V.step(a)
+        np.testing.assert_array_equal(_bits(ro), _bits(rv), err_msg='rewards t=%d' % t)
+        if restart_every and (t + 1) % restart_every == 0:   # restart(): counters and droplets back, maps (and the log) untouched
+            m = (rng.random(E) < 0.7).astype(np.uint8)
+            O.restart(mask=m); V.restart(mask=m)
+        if reset_every and (t + 1) % reset_every == 0:       # reset(new=False): log folded in, then updateHealth
+            m = (rng.random(E) < 0.5).astype(np.uint8)
+            O.reset(mask=m); V.reset(mask=m)
+            np.testing.assert_array_equal(_bits(O.get_map('health')), _bits(V.get_map('health')), err_msg='health t=%d' % t)
+        if set_usage_at is not None and t == set_usage_at:
+            u1 = rng.integers(0, 60, (E, cfg['width'], cfg['length'])).astype(np.float64)
+            O.set_map('usage', u1); V.set_map('usage', u1)
+        if (t + 1) % check_every == 0:
+            np.testing.assert_array_equal(O.get_map('usage'), V.get_map('usage'), err_msg='usage t=%d' % t)
+    np.testing.assert_array_equal(O.get_map('usage'), V.get_map('usage'))
+    np.testing.assert_array_equal(_bits(O.get_map('health')), _bits(V.get_map('health')))
+
+
+def test_usage_log_fills_up_without_reset():
+    # max_step = 2*(12+9) = 42 log slots; 150 steps with restart() only: the log is folded in every time it is full
+    _usage_log_walk(dict(width=12, length=9, n_agents=3, fov=7, with_maps=True), E=70, steps=150, seed=5, restart_every=11,
+                    check_every=150)
+
+
+def test_usage_map_read_and_replaced_mid_episode():
+    _usage_log_walk(dict(width=10, length=10, n_agents=4, fov=9, b_degrade=True, per_degrade=1.0), E=33, steps=120, seed=6,
+                    restart_every=0, check_every=7, set_usage_at=31, reset_every=25)
+
+
+def test_usage_log_large_chip_global_atomic_path():
+    # 80 x 70 = 5600 cells: above the LDS-histogram limit, the log is folded in with 32-bit global atomics on the u16 pairs
+    _usage_log_walk(dict(width=80, length=70, n_agents=5, fov=5, b_degrade=True, per_degrade=0.5), E=9, steps=330, seed=7,
+                    restart_every=0, check_every=100, reset_every=60)
