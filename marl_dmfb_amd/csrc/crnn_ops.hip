@@ -524,6 +524,25 @@ bool use_valu_conv() {  // CRNN_CONV_IMPL=valu selects the f32 VALU kernel (k_co
     return v;
 }
 
+// The dynamic-LDS limit is an attribute of the function ON ONE DEVICE: remember per device whether it has been raised
+// (a process may drive several GPUs; one rank per GPU is the normal case).  Thread-compatible like the rest of the ABI.
+struct PerDeviceOnce {
+    bool done[64] = {};
+    static int device() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return dev;
+    }
+    bool need() const {
+        const int dev = device();
+        return dev < 0 || dev >= 64 || !done[dev];
+    }
+    void mark() {
+        const int dev = device();
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+};
+
 template <int OD>
 int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w2,
            const float *b2, float *out, long out_stride, const int8_t *onehot, int n_actions, const float *mlp_w,
@@ -532,12 +551,12 @@ int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const
     using GM = crnn_mfma::GeoM<OD>;
     const bool valu = use_valu_conv();
     const size_t lds = (valu ? G::LDS_FLOATS : GM::LDS_FLOATS) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = valu ? hipFuncSetAttribute((const void *)k_conv9<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                             : hipFuncSetAttribute((const void *)crnn_mfma::k_conv9_mfma<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
-        attr_set = true;
+        attr_set.mark();
     }
     const int rb = valu ? G::RB : GM::RB;
     const long n_blocks = (rows + rb - 1) / rb;
@@ -565,11 +584,11 @@ int launch_bwd(const int8_t *obs, long obs_stride, long rows, const float *a1_sa
                hipStream_t s) {
     using G = GeoB<OD>;
     const size_t lds = G::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void *)k_conv9_bwd<OD, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
-        attr_set = true;
+        attr_set.mark();
     }
     (void)hipGetLastError();
     hipLaunchKernelGGL((k_conv9_bwd<OD, RC>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, a1_save, a2, a2_stride, g, g_stride,
@@ -586,11 +605,11 @@ int launch_bwd_mfma(const int8_t *obs, long obs_stride, long rows, const float *
                     const float *w1, const float *b1, const float *w2, float *part, int grid, float *grads, hipStream_t s) {
     using G = crnn_mfma::GeoMB<OD>;
     const size_t lds = G::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void *)crnn_mfma::k_conv9_bwd_mfma<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
-        attr_set = true;
+        attr_set.mark();
     }
     (void)hipGetLastError();
     hipLaunchKernelGGL((crnn_mfma::k_conv9_bwd_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockB), lds, s, obs, obs_stride, rows, a2, a2_stride, g,

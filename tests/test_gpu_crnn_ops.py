@@ -10,6 +10,26 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _safe_rows(net, obs, margin=2e-5):
+    """Rows none of whose conv pre-activations lies within `margin` of zero (float64 forward of the same weights).
+    A pre-activation at rounding distance from zero can get a different ReLU mask in fp32 than in the float64
+    reference, which moves a gradient sum by that element's whole contribution; the gradient tests give such rows (a
+    handful in 20 000) a zero upstream gradient, so that what is compared is summation error only."""
+    c1, c2 = net.convs
+    x = obs[:, :243].double().view(-1, 3, 9, 9)
+    z1 = torch.nn.functional.conv2d(x, c1.weight.double(), c1.bias.double())
+    z2 = torch.nn.functional.conv2d(torch.relu(z1), c2.weight.double(), c2.bias.double())
+    R = obs.shape[0]
+    return (z1.abs().reshape(R, -1).min(dim=1).values > margin) & (z2.abs().reshape(R, -1).min(dim=1).values > margin)
+
+
+GRAD_TOL = 5e-6  # relative L2 of an fp32 gradient tensor against the float64 reference (measured: <= 6e-7)
+
+
+def _rel_l2(g, r):
+    return float(np.linalg.norm(g.astype(np.float64) - r) / max(np.linalg.norm(r), 1e-30))
+
+
 @pytest.mark.parametrize('od,rows', [(24, 16384), (32, 4097), (24, 7), (32, 1)])
 def test_conv9_forward_matches_torch(od, rows):
     from marl_dmfb_amd.network.base_net import CRNN
@@ -56,6 +76,9 @@ def test_conv9_training_pair_matches_torch_autograd(od, rows):
     net = CRNN(a).cuda()
     obs = torch.randint(-3, 8, (rows, 245), dtype=torch.int8, device='cuda')
     gout = torch.randn(rows, od * 25, device='cuda')
+    safe = _safe_rows(net, obs)
+    assert safe.float().mean() > 0.8 or rows < 100
+    gout = gout * safe[:, None]
     c1, c2 = net.convs
     pix = _ConvFront9.apply(obs, c1.weight, c1.bias, c2.weight, c2.bias)
     (pix * gout).sum().backward()
@@ -68,14 +91,12 @@ def test_conv9_training_pair_matches_torch_autograd(od, rows):
     np.testing.assert_allclose(pix.detach().cpu().numpy(), x.reshape(rows, -1).detach().numpy(), rtol=1e-4, atol=1e-4)
     (x.reshape(rows, -1) * gout.double().cpu()).sum().backward()
     rc1, rc2 = ref_net.convs
-    # Tolerance: relative L2 error < 2e-3 and max abs error < 1e-2 x max|grad| per tensor.  The reference is
-    # float64; an fp32 pre-activation within rounding distance of zero can flip its ReLU mask (observed: one
-    # element in 12 million), which moves a gradient sum by that element's whole contribution.
-    for g, r in zip(got, (rc1.weight.grad, rc1.bias.grad, rc2.weight.grad, rc2.bias.grad)):
-        r = r.float().numpy()
-        g = g.numpy()
-        assert np.linalg.norm(g - r) <= 2e-3 * np.linalg.norm(r)
-        assert np.abs(g - r).max() <= 1e-2 * np.abs(r).max()
+    # float64 reference, rows with a knife-edge ReLU excluded (_safe_rows): what remains is fp32 summation error of
+    # sums over rows x 25 positions -> relative L2 <= GRAD_TOL per tensor
+    for name, g, r in zip(('w1', 'b1', 'w2', 'b2'), got, (rc1.weight.grad, rc1.bias.grad, rc2.weight.grad, rc2.bias.grad)):
+        err = _rel_l2(g.numpy(), r.numpy())
+        print('conv9 pair od=%d rows=%d %s rel_l2=%.2e' % (od, rows, name, err))
+        assert err <= GRAD_TOL, (name, err)
 
 
 @pytest.mark.parametrize('T,R', [(1, 1), (5, 13), (40, 2048), (17, 520)])
@@ -139,8 +160,8 @@ def test_recurrent_seq_hip_equals_aten_path():
 @pytest.mark.parametrize('od,rows', [(24, 20000), (32, 5003), (24, 11), (24, 8), (24, 2563)])
 def test_front9_train_node_matches_torch_autograd(od, rows, bwd, monkeypatch):
     """_Front9Train (fused forward incl. mlp1; VALU backward on saved activations, or the MFMA backward that recomputes
-    conv1) against float64 torch autograd of the reference network's front end (network/base_net.py:59-68).  Same
-    tolerance rationale as the VALU pair above."""
+    conv1) against float64 torch autograd of the reference network's front end (network/base_net.py:59-68); rows with a
+    knife-edge ReLU get a zero upstream gradient (_safe_rows), tolerance GRAD_TOL."""
     from marl_dmfb_amd.network.base_net import CRNN, _Front9Train
     monkeypatch.setenv('CRNN_CONV_BWD', bwd)
     a = types.SimpleNamespace(obs_shape=(3, 9, 9, 2, 245), hyper_hidden_dim=od, rnn_hidden_dim=128, n_actions=5, fov=9)
@@ -149,6 +170,8 @@ def test_front9_train_node_matches_torch_autograd(od, rows, bwd, monkeypatch):
     obs = torch.randint(-3, 8, (rows, 245), dtype=torch.int8, device='cuda')
     oh = torch.nn.functional.one_hot(torch.randint(0, 5, (rows,), device='cuda'), 5).to(torch.int8)
     gout = torch.randn(rows, od * 25 + 10, device='cuda')
+    safe = _safe_rows(net, obs)
+    gout = gout * safe[:, None]
     c1, c2 = net.convs
     x = _Front9Train.apply(obs, oh, c1.weight, c1.bias, c2.weight, c2.bias, net.mlp1.weight, net.mlp1.bias)
     (x * gout).sum().backward()
@@ -161,8 +184,8 @@ def test_front9_train_node_matches_torch_autograd(od, rows, bwd, monkeypatch):
     np.testing.assert_allclose(x.detach().cpu().numpy(), xr.detach().numpy(), rtol=1e-4, atol=1e-4)
     (xr * gout.double().cpu()).sum().backward()
     r1, r2 = ref.convs
-    for g, r in zip(got, (r1.weight.grad, r1.bias.grad, r2.weight.grad, r2.bias.grad, ref.mlp1.weight.grad, ref.mlp1.bias.grad)):
-        r = r.float().numpy()
-        g = g.numpy()
-        assert np.linalg.norm(g - r) <= 2e-3 * np.linalg.norm(r)
-        assert np.abs(g - r).max() <= 1e-2 * np.abs(r).max()
+    for name, g, r in zip(('w1', 'b1', 'w2', 'b2', 'mlp_w', 'mlp_b'), got,
+                          (r1.weight.grad, r1.bias.grad, r2.weight.grad, r2.bias.grad, ref.mlp1.weight.grad, ref.mlp1.bias.grad)):
+        err = _rel_l2(g.numpy(), r.numpy())
+        print('front9 %s od=%d rows=%d %s rel_l2=%.2e' % (bwd, od, rows, name, err))
+        assert err <= GRAD_TOL, (name, err)

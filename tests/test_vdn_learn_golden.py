@@ -2,9 +2,12 @@
 deterministic weights must reproduce the reference's clipped gradients, gradient norms and
 updated weights (policy/vdn.py:79-132 run in this container, see tools/oracle/gen_vdn_golden.py).
 
-Tolerance: rtol 2e-4 on values, atol 2e-5 x max|grad| per tensor.  The build batches the
-convolutions over all T steps and runs the target net under no_grad, so summation order differs
-from the reference's per-step loop; everything else is the same arithmetic."""
+Tolerance (1e-5 relative), the same on CPU and GPU: |g - ref| <= 1e-5 x max|ref| + 1e-5 x |ref| per
+sampled gradient element, 1e-5 relative on the gradient norm.  The build batches the convolutions over all T steps, runs
+the target net under no_grad, and on the GPU goes through the HIP front end, split-K weight gradients and the one-launch
+GRU kernels, so summation order differs from the reference's per-step loop; everything else is the same arithmetic.
+Measured (tools/diag_learn_tol.py): max|g - ref| / max|ref| <= 1.8e-6 on the CPU and <= 1.4e-6 on MI355X for every
+parameter tensor, with the HIP GRU or the per-step aten cell, with the HIP conv front end or the im2col GEMM path."""
 import glob
 import os
 
@@ -17,10 +20,10 @@ FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'vdn_
 
 @pytest.mark.parametrize('path', FILES, ids=os.path.basename)
 def test_learn_matches_reference_cpu(path):
-    learn_golden_check(path, 'cpu', rtol=2e-4, atol=2e-5)
+    learn_golden_check(path, 'cpu', rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('path', FILES, ids=os.path.basename)
 def test_learn_matches_reference_gpu(path):
-    learn_golden_check(path, 'cuda:0', rtol=2e-3, atol=2e-4)
+    learn_golden_check(path, 'cuda:0', rtol=1e-5, atol=1e-5)
