@@ -16,8 +16,8 @@ Workload (BASELINE.json configs[1]): DMFB 10x10, 4 droplets, fov 9, 4096 chips p
 tasks from the Philox generator, randomly initialised CRNN (hyper_hidden_dim 24, fp32).
 
 `roofline` describes the FOV-gather kernel `dmfbk::k_observe<n>` (the kernel BASELINE.json's
-north_star grades) at `--roofline_envs` chips per launch, timed live with HIP events on the launch
-stream; nothing is subtracted from the event figures.  The same kernel inside the 4096-chip training
+north_star grades) at `--roofline_envs` chips per launch, timed live with HIP events that carry the
+dispatch's own time stamps; nothing is subtracted from the event figures.  The same kernel inside the 4096-chip training
 loop is launch-latency bound and is reported under `tiers.in_loop_step_kernel`.
 """
 import argparse
@@ -112,9 +112,11 @@ def launch_ranks(a, argv):
 # tiers measured on the GPU
 # ------------------------------------------------------------------------------------------------
 def env_only_tier(cfg, E, iters, device, fov_kernel=False):
-    """Env-only tier: transition + observation with auto-reset, uniform random actions.  With
-    fov_kernel=True also the FOV-gather kernel alone (k_observe), `iters` launches back to back between two
-    HIP events on the launch stream (the average therefore includes the ~1.5 us kernel boundary)."""
+    """Env-only tier: transition + observation with auto-reset, uniform random actions, `iters` lock-steps between two
+    HIP events.  With fov_kernel=True the FOV-gather kernel (k_observe, the second launch of every lock-step at this
+    batch size) is timed inside that same loop: each of its launches carries a HIP event pair that receives the
+    dispatch's own start/end time stamps (include/dmfb_vec.h: dmfb_vec_observe_timing) -- the per-kernel duration
+    rocprofv3 --kernel-trace reports for the same command."""
     from marl_dmfb_amd.env.dmfb import VecDMFB
     env = VecDMFB(n_envs=E, seed=1, device=device, **cfg)
     env.reset()
@@ -124,6 +126,8 @@ def env_only_tier(cfg, E, iters, device, fov_kernel=False):
         env.step(acts[i % 8], autoreset=True)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if fov_kernel:
+        env.observe_timing(True)
     e0.record()
     for i in range(iters):
         env.step(acts[i % 8], autoreset=True)
@@ -135,7 +139,22 @@ def env_only_tier(cfg, E, iters, device, fov_kernel=False):
            'algo_bytes_per_env_step': b, 'algo_GBps': round(E * b / us / 1e3, 1),
            'frac': round(E * b / us / 1e3 / HBM_PEAK_GBPS, 4)}
     if fov_kernel:
-        for _ in range(10):
+        tot_us, launches = env.observe_timing_read()
+        where = 'inside the env-only lock-step loop (step-only kernel + this kernel per lock-step)'
+        if launches == 0:  # small batch: the lock-step is ONE fused launch; time the standalone observation launches instead
+            for i in range(iters):
+                env.observe()
+            tot_us, launches = env.observe_timing_read()
+            where = 'standalone launches (at this batch the lock-step is one fused kernel)'
+        env.observe_timing(False)
+        kus = tot_us / launches
+        fb = fov_kernel_bytes_per_env(cfg['n_agents'], cfg['fov'])
+        out['fov_kernel'] = {'kernel': 'dmfbk::k_observe<%d>' % cfg['n_agents'], 'launches_timed': launches, 'where': where,
+                             'us_per_launch': round(kus, 2), 'algo_bytes_per_env': fb,
+                             'algo_GBps': round(E * fb / kus / 1e3, 1), 'frac': round(E * fb / kus / 1e3 / HBM_PEAK_GBPS, 4)}
+        # the same kernel launched back to back (nothing in between): every launch then also waits for the previous
+        # launch's dirty L2 lines to be written back, which otherwise overlaps the (latency-bound) transition kernel
+        for _ in range(5):
             env.observe()
         torch.cuda.synchronize()
         e0.record()
@@ -143,11 +162,7 @@ def env_only_tier(cfg, E, iters, device, fov_kernel=False):
             env.observe()
         e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / iters
-        fb = fov_kernel_bytes_per_env(cfg['n_agents'], cfg['fov'])
-        out['fov_kernel'] = {'kernel': 'dmfbk::k_observe<%d>' % cfg['n_agents'], 'launches_timed': iters,
-                             'us_per_launch': round(us, 2), 'algo_bytes_per_env': fb,
-                             'algo_GBps': round(E * fb / us / 1e3, 1), 'frac': round(E * fb / us / 1e3 / HBM_PEAK_GBPS, 4)}
+        out['fov_kernel']['back_to_back_us_per_launch'] = round(e0.elapsed_time(e1) * 1e3 / iters, 2)
     env.close()
     return out
 
@@ -452,7 +467,9 @@ def main(argv=None):
                            'unit': 'GB/s', 'frac': fk['frac'], 'traffic': traffic, 'envs_per_launch': a.roofline_envs,
                            'algo_bytes_per_env': fk['algo_bytes_per_env'], 'avg_launch_us': fk['us_per_launch'],
                            'launches_timed': fk['launches_timed'],
-                           'timing': 'HIP events on the launch stream around %d back-to-back launches, nothing subtracted' % fk['launches_timed']}
+                           'back_to_back_avg_launch_us': fk['back_to_back_us_per_launch'],
+                           'timing': 'HIP event pair per launch carrying the dispatch start/end time stamps, %d launches, %s; nothing '
+                                     'subtracted' % (fk['launches_timed'], fk['where'])}
         if not a.no_tiers and world == 1:
             tiers['env_only_large_batch'] = big
             tiers['env_only_%d' % a.n_envs] = env_only_tier(cfg, a.n_envs, 300, device)

@@ -138,10 +138,17 @@ int dmfb_vec_get_map(const dmfb_vec *h, int which, double *d_buf, void *stream);
 int dmfb_vec_set_map(dmfb_vec *h, int which, const double *d_buf, void *stream);
 
 /* How the handle maps chips to workgroups (profiling aid; no reference counterpart): out[0] = chips per 256-thread
- * workgroup of the fused step+observe launch, out[1] = chips per workgroup of the observation kernel, out[2] = batch size
+ * workgroup of the fused step+observe launch, out[1] = chips per tile of the observation kernel, out[2] = batch size
  * from which dmfb_vec_step issues a step-only launch followed by the observation kernel, out[3] = chips per workgroup of
- * that step-only launch. */
-int dmfb_vec_launch_shape(const dmfb_vec *h, int32_t out[4]);
+ * that step-only launch, out[4] = workgroups of the (persistent) observation kernel, out[5] = its threads per workgroup. */
+int dmfb_vec_launch_shape(const dmfb_vec *h, int32_t out[6]);
+
+/* Measurement aid (no reference counterpart): while enabled, every launch of the observation kernel (standalone or as the
+ * second launch of dmfb_vec_step at large batches) carries a HIP event pair that receives the dispatch's own start and end
+ * time stamps -- the duration rocprofv3 --kernel-trace reports.  _read waits for the timed launches (host-synchronising),
+ * returns their summed duration in microseconds and their count (at most 256 per read) and starts a new series. */
+int dmfb_vec_observe_timing(dmfb_vec *h, int enable);
+int dmfb_vec_observe_timing_read(dmfb_vec *h, double *total_us, int *launches);
 
 /* Direction-vector zoom table (dmfb.py:444-453) the handle was built with: int8[2][511], host memory. */
 int dmfb_vec_zoom_lut(const dmfb_vec *h, int8_t *host_out);

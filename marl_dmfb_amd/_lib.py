@@ -49,7 +49,7 @@ DMFB_VEC_SYMBOLS = [
     'dmfb_vec_check_config', 'dmfb_vec_create', 'dmfb_vec_destroy', 'dmfb_vec_state_bytes', 'dmfb_vec_obs_len',
     'dmfb_vec_max_step', 'dmfb_vec_n_envs', 'dmfb_vec_n_agents', 'dmfb_vec_reset', 'dmfb_vec_restart',
     'dmfb_vec_set_task', 'dmfb_vec_get_task', 'dmfb_vec_set_blocks', 'dmfb_vec_get_blocks', 'dmfb_vec_step', 'dmfb_vec_observe', 'dmfb_vec_get_state',
-    'dmfb_vec_get_map', 'dmfb_vec_set_map', 'dmfb_vec_launch_shape', 'dmfb_vec_zoom_lut', 'dmfb_vec_strerror', 'dmfb_vec_last_hip_error',
+    'dmfb_vec_get_map', 'dmfb_vec_set_map', 'dmfb_vec_launch_shape', 'dmfb_vec_observe_timing', 'dmfb_vec_observe_timing_read', 'dmfb_vec_zoom_lut', 'dmfb_vec_strerror', 'dmfb_vec_last_hip_error',
 ]
 
 
@@ -78,7 +78,9 @@ def dmfb_vec():
     lib.dmfb_vec_get_map.argtypes = [vp, i32, vp, vp]
     lib.dmfb_vec_set_map.argtypes = [vp, i32, vp, vp]
     lib.dmfb_vec_zoom_lut.argtypes = [vp, vp]
-    lib.dmfb_vec_launch_shape.argtypes = [vp, C.POINTER(C.c_int32 * 4)]
+    lib.dmfb_vec_launch_shape.argtypes = [vp, C.POINTER(C.c_int32 * 6)]
+    lib.dmfb_vec_observe_timing.argtypes = [vp, i32]
+    lib.dmfb_vec_observe_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.dmfb_vec_strerror.argtypes = [i32]
     lib.dmfb_vec_strerror.restype = C.c_char_p
     lib.dmfb_vec_last_hip_error.argtypes = []

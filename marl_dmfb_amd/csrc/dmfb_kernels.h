@@ -1031,6 +1031,6 @@ template <int N>
 hipError_t launch_reset_n(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int mode, int grid, size_t lds, hipStream_t s);
 template <int N>
 hipError_t launch_observe_n(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int8_t *obs, int grid, size_t lds,
-                            hipStream_t s);
+                            hipStream_t s, hipEvent_t t0, hipEvent_t t1);  // t0/t1 non-null: dispatch start/stop time stamps
 
 }  // namespace dmfbk

@@ -2,6 +2,7 @@
 // N-independent kernels (observation, task/state/map accessors) and the dispatch to the per-N
 // transition/reset kernels built from dmfb_vec_n.hip.  Device code: dmfb_kernels.h.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdint>
@@ -174,6 +175,10 @@ struct dmfb_vec {
     int split_min = 0;   // batches of at least this many chips use the step-only + observe pair
     int T_min = 16;      // smallest tile pick_tile may choose (DMFB_VEC_MIN_TILE); smaller tiles do not pay off (measured)
     int n_cu = 256;      // compute units of the device (persistent grid of the observation kernel)
+    // dmfb_vec_observe_timing: event pairs that receive the dispatch time stamps of the observation kernel
+    static constexpr int kTimed = 256;
+    hipEvent_t ev[2 * kTimed] = {};
+    int timing = 0, timed = 0;
 };
 
 namespace {
@@ -211,7 +216,13 @@ template <int N> int observe_n(const dmfb_vec *h, const uint8_t *mask, int8_t *o
     per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
     const int ntiles = (h->cfg.n_envs + T - 1) / T;
     const int grid = ntiles < h->n_cu * per_cu ? ntiles : h->n_cu * per_cu;
-    HIP_TRY(launch_observe_n<N>(h->dc, h->dp, mask, obs, grid, lds, s));
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    dmfb_vec *hm = const_cast<dmfb_vec *>(h);
+    if (h->timing && h->timed < dmfb_vec::kTimed) {
+        t0 = hm->ev[2 * h->timed]; t1 = hm->ev[2 * h->timed + 1];
+        hm->timed += 1;
+    }
+    HIP_TRY(launch_observe_n<N>(h->dc, h->dp, mask, obs, grid, lds, s, t0, t1));
     return DMFB_OK;
 }
 
@@ -417,6 +428,8 @@ int dmfb_vec_destroy(dmfb_vec *h) {
     (void)hipFree(h->dp.st); (void)hipFree(h->dp.starts); (void)hipFree(h->dp.health);
     (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage); (void)hipFree(h->dp.ulog); (void)hipFree(h->zoom_dev); (void)hipFree(h->dp.blocks);
     (void)hipFree(h->band_dev);
+    for (int i = 0; i < 2 * dmfb_vec::kTimed; ++i)
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
     return DMFB_OK;
 }
@@ -547,9 +560,40 @@ int dmfb_vec_set_map(dmfb_vec *h, int which, const double *d_buf, void *stream) 
     return DMFB_OK;
 }
 
-int dmfb_vec_launch_shape(const dmfb_vec *h, int32_t out[4]) {
+int dmfb_vec_launch_shape(const dmfb_vec *h, int32_t out[6]) {
     if (!h || !out) return DMFB_ERR_BAD_ARG;
     out[0] = h->T_fused; out[1] = h->T_obs; out[2] = h->split_min; out[3] = kStepOnlyTile;
+    const size_t lds = tile_lds_bytes(h->T_obs, h->cfg.n_agents, h->dc.obs_len, true, table_words(h->dc.hf, h->dc.nq));
+    int per_cu = (int)((size_t)160 * 1024 / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    const int ntiles = (h->cfg.n_envs + h->T_obs - 1) / h->T_obs;
+    out[4] = ntiles < h->n_cu * per_cu ? ntiles : h->n_cu * per_cu;
+    out[5] = kObsBlock;
+    return DMFB_OK;
+}
+
+int dmfb_vec_observe_timing(dmfb_vec *h, int enable) {
+    if (!h) return DMFB_ERR_BAD_ARG;
+    DeviceGuard g(h->cfg.device);
+    if (enable && !h->ev[0])
+        for (int i = 0; i < 2 * dmfb_vec::kTimed; ++i) HIP_TRY(hipEventCreate(&h->ev[i]));
+    h->timing = enable != 0;
+    h->timed = 0;
+    return DMFB_OK;
+}
+
+int dmfb_vec_observe_timing_read(dmfb_vec *h, double *total_us, int *launches) {
+    if (!h || !total_us || !launches) return DMFB_ERR_BAD_ARG;
+    DeviceGuard g(h->cfg.device);
+    double sum = 0.0;
+    for (int i = 0; i < h->timed; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(h->ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+        sum += (double)ms * 1e3;
+    }
+    *total_us = sum; *launches = h->timed;
+    h->timed = 0;
     return DMFB_OK;
 }
 

@@ -1,5 +1,7 @@
 // dmfb_vec_n.hip -- instantiates the transition and reset kernels for ONE droplet count
 // (compile with -DDMFB_TU_N=<n>); see dmfb_kernels.h.
+#include <hip/hip_ext.h>
+
 #include "dmfb_kernels.h"
 
 #ifndef DMFB_TU_N
@@ -27,9 +29,12 @@ hipError_t launch_reset_n<DMFB_TU_N>(const DevCfg &c, const DevPtrs &p, const ui
 
 template <>
 hipError_t launch_observe_n<DMFB_TU_N>(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int8_t *obs, int grid,
-                                       size_t lds, hipStream_t s) {
+                                       size_t lds, hipStream_t s, hipEvent_t t0, hipEvent_t t1) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_observe<DMFB_TU_N>), dim3(grid), dim3(kObsBlock), lds, s, c, p, mask, obs);
+    if (t0 && t1)  // the events receive the dispatch's own start/end time stamps (what rocprofv3 --kernel-trace reports)
+        hipExtLaunchKernelGGL((k_observe<DMFB_TU_N>), dim3(grid), dim3(kObsBlock), lds, s, t0, t1, 0, c, p, mask, obs);
+    else
+        hipLaunchKernelGGL((k_observe<DMFB_TU_N>), dim3(grid), dim3(kObsBlock), lds, s, c, p, mask, obs);
     return hipGetLastError();
 }
 

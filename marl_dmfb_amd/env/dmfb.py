@@ -217,9 +217,20 @@ class VecDMFB:
 
     def launch_shape(self):
         """Chips per workgroup of the launches the handle makes (include/dmfb_vec.h: dmfb_vec_launch_shape)."""
-        out = (C.c_int32 * 4)()
+        out = (C.c_int32 * 6)()
         _check(self.lib.dmfb_vec_launch_shape(self.h, C.byref(out)))
-        return {'fused_tile': out[0], 'observe_tile': out[1], 'split_min_envs': out[2], 'step_only_tile': out[3]}
+        return {'fused_tile': out[0], 'observe_tile': out[1], 'split_min_envs': out[2], 'step_only_tile': out[3],
+                'observe_workgroups': out[4], 'observe_block': out[5]}
+
+    def observe_timing(self, enable):
+        """Start/stop collecting the dispatch time stamps of the observation kernel (dmfb_vec_observe_timing)."""
+        _check(self.lib.dmfb_vec_observe_timing(self.h, int(bool(enable))))
+
+    def observe_timing_read(self):
+        """(summed kernel duration in microseconds, launches) since the last read; synchronises the host."""
+        us, n = C.c_double(0.0), C.c_int(0)
+        _check(self.lib.dmfb_vec_observe_timing_read(self.h, C.byref(us), C.byref(n)))
+        return us.value, n.value
 
     def zoom_lut(self):
         out = np.zeros((2, 511), np.int8)

@@ -52,7 +52,7 @@ def launch_labels(name, cfg, env, E):
         out['dmfbk::k_step<%d, %s>|%d' % (n, maps, wgs(sh['step_only_tile']))] = {'key': 'k_step_only_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (algo_bytes(cfg) - ob) * E}
     else:
         out['dmfbk::k_step<%d, %s>|%d' % (n, maps, wgs(sh['fused_tile']))] = {'key': 'k_step_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': algo_bytes(cfg) * E}
-    out['dmfbk::k_observe<%d>|%d' % (n, wgs(sh['observe_tile']))] = {'key': 'k_observe_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (ob + 5 * n + 8) * E}
+    out['dmfbk::k_observe<%d>|%d' % (n, sh['observe_workgroups'] * sh['observe_block'])] = {'key': 'k_observe_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (ob + 5 * n + 8) * E}
     return out
 
 
