@@ -879,8 +879,13 @@ __global__ __launch_bounds__(kObsBlock) void k_observe(DevCfg c, DevPtrs p, cons
         const bool on = tile < ntiles && ltid < min(T, E - base);
 #pragma unroll
         for (int w = 0; w < NP; ++w) {
+#ifdef DMFB_ABLATE_LOADS  // timing experiment: no global reads while the tiles stream out (wrong observations)
+            pw[w] = on ? (uint32_t)(base + ltid) * 0x01010101u & 0x07070707u : 0u;
+            gw[w] = pw[w] ^ 0x01000100u;
+#else
             pw[w] = on ? p.st[(size_t)w * E + base + ltid] : 0u;
             gw[w] = on ? p.st[(size_t)(NP + w) * E + base + ltid] : 0u;
+#endif
         }
     };
     const Tile t0 = carve(smem, T, N, c.obs_len, true, table_words(c.hf, c.nq), 0);
