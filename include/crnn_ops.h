@@ -38,38 +38,18 @@ int crnn_conv9_forward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, co
 int crnn_front9_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
                         const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
                         const float *d_mlp_b, int od, float *d_out, int64_t out_stride, void *stream);
-/* Training pair for the eval network of VDN.learn (policy/vdn.py:174-191): same forward, additionally
- * saving the conv1 activations d_a1_save float32[rows][crnn_conv9_a1_floats(od)]; the backward forms the
- * gradients of the four parameter tensors (the observation needs none): one workgroup per partial
- * vector accumulates over its rows into d_part float32[n_part][crnn_conv9_backward_parts(od)] (scratch,
- * n_part <= 256), then a second small kernel adds the partial vectors (fixed order: deterministic) into
- * d_grads float32[od*od*9 + od + od*27 + od] = dW2[od][od][3][3] | db2[od] | dW1[od][3][3][3] | db1[od].
- * d_out is the forward's output (its sign is the ReLU mask), d_grad_out the gradient w.r.t. it. */
-int crnn_conv9_forward_train(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_w1, const float *d_b1,
-                             const float *d_w2, const float *d_b2, int od, float *d_out, int64_t out_stride, float *d_a1_save,
-                             void *stream);
-/* crnn_front9_forward + the saved conv1 activations: the whole GRU input row for the eval network in one launch. */
-int crnn_front9_forward_train(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
-                              const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
-                              const float *d_mlp_b, int od, float *d_out, int64_t out_stride, float *d_a1_save, void *stream);
+/* Gradients of the four conv tensors for the eval network of VDN.learn (policy/vdn.py:123-128 backward through
+ * network/base_net.py:63-65); the observation needs none.  Nothing is saved by the forward: the conv1 activations of each
+ * row block are recomputed inside the kernel (f32 MFMA, as the forward computes them) and the next block's inputs are
+ * prefetched while the current one is reduced.  d_out is the forward's output (crnn_conv9_forward or crnn_front9_forward;
+ * its sign is the ReLU mask), d_grad_out the gradient w.r.t. it.  One workgroup per partial vector accumulates over its
+ * rows into d_part float32[n_part][crnn_conv9_backward_parts(od)] (scratch, n_part <= 256), then a second small kernel
+ * adds the partial vectors (fixed order: deterministic) into
+ * d_grads float32[od*od*9 + od + od*27 + od] = dW2[od][od][3][3] | db2[od] | dW1[od][3][3][3] | db1[od]. */
 int crnn_conv9_backward_parts(int od);
-int crnn_conv9_a1_floats(int od);
-int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_a1_save, const float *d_out,
-                        int64_t out_stride, const float *d_grad_out, int64_t grad_stride, const float *d_w2, int od,
-                        float *d_part, int n_part, float *d_grads, void *stream);
-/* crnn_conv9_backward without d_a1_save: the conv1 activations of each row block are recomputed inside the kernel (f32
- * MFMA, as the forward computes them) and the next block's inputs are prefetched while the current one is reduced; used
- * with crnn_front9_forward / crnn_conv9_forward (nothing saved).  d_part as crnn_conv9_backward. */
-int crnn_conv9_backward_rc(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
-                           const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1, const float *d_w2,
-                           int od, float *d_part, int n_part, float *d_grads, void *stream);
-/* Experimental: the same gradients with all three contractions on MFMA: conv1 is recomputed per row block on the matrix cores, the three
- * gradient contractions run as f32 MFMA GEMMs (csrc/crnn_mfma_bwd.h).  d_out / d_grad_out as above;
- * d_part float32[n_part][crnn_conv9_backward_mfma_parts(od)] scratch (n_part <= 256). */
-int crnn_conv9_backward_mfma_parts(int od);
-int crnn_conv9_backward_mfma(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
-                             const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1,
-                             const float *d_w2, int od, float *d_part, int n_part, float *d_grads, void *stream);
+int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
+                        const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1, const float *d_w2,
+                        int od, float *d_part, int n_part, float *d_grads, void *stream);
 int crnn_last_hip_error(void);
 
 /* ---- GRU cell unrolled over an episode (network/base_net.py:56,69 nn.GRUCell; policy/vdn.py:174-191 time loop) ----

@@ -94,8 +94,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
                                                         const float *__restrict__ w2, const float *__restrict__ b2,
                                                         float *__restrict__ out, long out_stride,
                                                         const int8_t *__restrict__ onehot, int n_actions,
-                                                        const float *__restrict__ mlp_w, const float *__restrict__ mlp_b,
-                                                        float *__restrict__ a1_save) {
+                                                        const float *__restrict__ mlp_w, const float *__restrict__ mlp_b) {
     using G = GeoM<OD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *s_in = lds;                              // [RB][244]  float image of the pixel bytes
@@ -227,13 +226,6 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
         if (mlp_w && tid < G::RB * 10) {
             mv = mlp_b[mc];
             for (int k = 0; k < nin; ++k) mv = fmaf(s_vec[mr * G::VEC + k], mlp_w[mc * nin + k], mv);
-        }
-        if (a1_save) {  // training: the backward kernel wants [row][channel][52] (crnn_conv9_a1_floats); a wave per (row, channel)
-            if (lane < 49)
-                for (int pc = wave; pc < rv * OD; pc += kBlockM / 64) {
-                    const int rr = pc / OD, c = pc - rr * OD;
-                    a1_save[((row0 + rr) * OD + c) * 52 + lane] = s_a1[rr * G::ROW_A1 + c * G::CS + lane];
-                }
         }
         // ---- conv2
 #ifndef CRNN_PROBE_SKIP_CONV2

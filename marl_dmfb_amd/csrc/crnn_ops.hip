@@ -19,7 +19,6 @@
 
 #include "../../include/crnn_ops.h"
 #include "crnn_mfma.h"
-#include "crnn_mfma_bwd.h"
 
 namespace {
 
@@ -27,134 +26,6 @@ constexpr int kBlock = 512;  // 8 waves: one workgroup per CU keeps ONE copy of 
 constexpr int kA1Stride = 52;  // 49 conv1 activations per (row, channel), padded to a 16-byte multiple
 
 constexpr int kLdsBudget = 158 * 1024;  // of the CU's 160 KiB
-
-template <int OD> struct Geo {
-    static constexpr int ROW_BYTES = (OD * kA1Stride + 4 + 244) * 4;               // a1 row + input row
-    static constexpr int FIXED_BYTES = (OD * OD * 9 + OD * 27 + 2 * OD) * 4;       // weights + biases
-    static constexpr int RB_LDS = (kLdsBudget - FIXED_BYTES) / ROW_BYTES;
-    static constexpr int RB = (kBlock / OD) < RB_LDS ? (kBlock / OD) : RB_LDS;      // rows per iteration (24 -> 21, 32 -> 15)
-    static constexpr int ROW_A1 = OD * kA1Stride + 4;   // +4 floats: rows start on different banks
-    static constexpr int IN_STRIDE = 244;               // 243 pixels (+1)
-    static constexpr size_t LDS_FLOATS = (size_t)OD * OD * 9 + OD * 27 + 2 * OD + (size_t)RB * IN_STRIDE + (size_t)RB * ROW_A1;
-};
-
-template <int OD>
-__global__ __launch_bounds__(kBlock) void k_conv9(const int8_t *__restrict__ obs, long obs_stride, long rows,
-                                                  const float *__restrict__ w1, const float *__restrict__ b1,
-                                                  const float *__restrict__ w2, const float *__restrict__ b2,
-                                                  float *__restrict__ out, long out_stride,
-                                                  const int8_t *__restrict__ onehot, int n_actions,
-                                                  const float *__restrict__ mlp_w, const float *__restrict__ mlp_b,
-                                                  float *__restrict__ a1_save) {
-    using G = Geo<OD>;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *s_w2 = lds;                         // [OD c1][9 tap][OD c2]: lanes (= c2) read consecutive banks
-    float *s_w1 = s_w2 + OD * OD * 9;          // [OD][27]
-    float *s_b1 = s_w1 + OD * 27;              // [OD]
-    float *s_b2 = s_b1 + OD;                   // [OD]
-    float *s_in = s_b2 + OD;                   // [RB][244]
-    float *s_a1 = s_in + G::RB * G::IN_STRIDE; // [RB][ROW_A1], 16-byte aligned by construction
-    const int tid = threadIdx.x;
-    for (int i = tid; i < OD * OD * 9; i += kBlock) {  // global (c2, c1, tap) -> LDS (c1, tap, c2)
-        const int c2 = i / (OD * 9), rem = i - c2 * OD * 9;
-        s_w2[rem * OD + c2] = w2[i];
-    }
-    for (int i = tid; i < OD * 27; i += kBlock) s_w1[i] = w1[i];
-    if (tid < OD) { s_b1[tid] = b1[tid]; s_b2[tid] = b2[tid]; }
-    const int r = tid / OD, c = tid - r * OD;  // row in block, output channel
-    const bool worker = r < G::RB;
-    const long n_blocks = (rows + G::RB - 1) / G::RB;
-    for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const long row0 = blk * G::RB;
-        const int rv = (int)min((long)G::RB, rows - row0);
-        __syncthreads();  // previous iteration's readers of s_in / s_a1 are done (and weights are loaded)
-        for (int i = tid; i < rv * 243; i += kBlock) {
-            const int rr = i / 243, p = i - rr * 243;
-            s_in[rr * G::IN_STRIDE + p] = (float)obs[(row0 + rr) * obs_stride + p];
-        }
-        __syncthreads();
-        if (worker && r < rv) {
-            // ---- conv1 + ReLU: out (7,7) for channel c of row r; input (3,9,9) in (c0,x,y) order
-            const float *in = s_in + r * G::IN_STRIDE;
-            float *a1 = s_a1 + r * G::ROW_A1 + c * kA1Stride;
-            float wv[27];
-#pragma unroll
-            for (int k = 0; k < 27; ++k) wv[k] = s_w1[c * 27 + k];
-            const float bias = s_b1[c];
-#pragma unroll 1
-            for (int x = 0; x < 7; ++x) {
-                float acc[7];
-#pragma unroll
-                for (int y = 0; y < 7; ++y) acc[y] = bias;
-#pragma unroll
-                for (int c0 = 0; c0 < 3; ++c0)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        float v[9];
-#pragma unroll
-                        for (int y = 0; y < 9; ++y) v[y] = in[c0 * 81 + (x + kx) * 9 + y];
-#pragma unroll
-                        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                            for (int y = 0; y < 7; ++y) acc[y] = fmaf(v[y + ky], wv[c0 * 9 + kx * 3 + ky], acc[y]);
-                    }
-#pragma unroll
-                for (int y = 0; y < 7; ++y) a1[x * 7 + y] = fmaxf(acc[y], 0.0f);
-                if (a1_save) {  // training: keep the conv1 activations for the backward kernel
-                    float *sv = a1_save + ((row0 + r) * OD + c) * kA1Stride + x * 7;  // padded like the LDS image
-#pragma unroll
-                    for (int y = 0; y < 7; ++y) sv[y] = fmaxf(acc[y], 0.0f);
-                }
-            }
-        }
-        __syncthreads();
-        if (worker && r < rv) {
-            // ---- conv2 + ReLU: out (5,5) for channel c of row r over OD input channels of (7,7)
-            float acc[25];
-            const float bias = s_b2[c];
-#pragma unroll
-            for (int k = 0; k < 25; ++k) acc[k] = bias;
-            const float *a1row = s_a1 + r * G::ROW_A1;
-            const float *wrow = s_w2 + c;
-#pragma unroll 2
-            for (int c1 = 0; c1 < OD; ++c1) {
-                float a[kA1Stride];
-                const float4 *src = (const float4 *)__builtin_assume_aligned(a1row + c1 * kA1Stride, 16);  // ds_read_b128
-#pragma unroll
-                for (int q = 0; q < kA1Stride / 4; ++q) {
-                    const float4 t = src[q];
-                    a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
-                }
-                float w[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) w[k] = wrow[(c1 * 9 + k) * OD];
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int x = 0; x < 5; ++x)
-#pragma unroll
-                            for (int y = 0; y < 5; ++y)
-                                acc[x * 5 + y] = fmaf(a[(x + kx) * 7 + y + ky], w[kx * 3 + ky], acc[x * 5 + y]);
-            }
-            float *o = out + (row0 + r) * out_stride + c * 25;
-#pragma unroll
-            for (int k = 0; k < 25; ++k) o[k] = fmaxf(acc[k], 0.0f);
-            if (mlp_w && c < 10) {  // vector branch: relu(mlp1([dir_x, dir_y, last-action one-hot])) (base_net.py:66)
-                const int nin = 2 + n_actions;
-                const int8_t *ob = obs + (row0 + r) * obs_stride;
-                float v = mlp_b[c];
-                v = fmaf((float)ob[243], mlp_w[c * nin], v);
-                v = fmaf((float)ob[244], mlp_w[c * nin + 1], v);
-                if (onehot)
-                    for (int k = 0; k < n_actions; ++k) v = fmaf((float)onehot[(row0 + r) * n_actions + k], mlp_w[c * nin + 2 + k], v);
-                out[(row0 + r) * out_stride + OD * 25 + c] = fmaxf(v, 0.0f);
-            }
-        }
-    }
-}
-
 
 // ---- backward of conv1+ReLU+conv2+ReLU w.r.t. the four parameter tensors (the int8 observation needs no
 // gradient).  One persistent 512-thread workgroup per CU walks blocks of RBB rows; every thread keeps
@@ -184,13 +55,12 @@ template <int OD> struct GeoB {
     static constexpr int PART = kBlock * 9 + kBlock * 9 + OD + kBlock * 3 + OD;
 };
 
-// RC = true: nothing was saved by the forward; the conv1 activations of each row block are recomputed on the matrix
-// cores (the forward's f32 MFMA tiling, crnn_mfma.h) and the next block's dz2 / pixel rows are fetched into registers
-// while phase P3 runs, so no HBM latency sits between two barriers.  RC = false: a1 comes from a1_save.
-template <int OD, bool RC>
+// Nothing is saved by the forward: the conv1 activations of each row block are recomputed on the matrix cores (the
+// forward's f32 MFMA tiling, crnn_mfma.h) and the next block's dz2 / pixel rows are fetched into registers while phase
+// P3 runs, so no HBM latency sits between two barriers.
+template <int OD>
 __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__ obs, long obs_stride, long rows,
-                                                      const float *__restrict__ a1_save, const float *__restrict__ a2,
-                                                      long a2_stride, const float *__restrict__ g, long g_stride,
+                                                      const float *__restrict__ a2, long a2_stride, const float *__restrict__ g, long g_stride,
                                                       const float *__restrict__ w2, float *__restrict__ part,
                                                       const float *__restrict__ w1, const float *__restrict__ b1) {
     using G = GeoB<OD>;
@@ -225,13 +95,13 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     const long per = (n_blocks + gridDim.x - 1) / gridDim.x;
     const long blk0 = (long)blockIdx.x * per, blk1 = min(n_blocks, blk0 + per);
 
-    // ---- RC: conv1 roles (wave = (channel half, row residue)), B operands, prefetch registers
+    // ---- conv1 roles (wave = (channel half, row residue)), B operands, prefetch registers
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int lane = tid & 63, wave = tid >> 6, j16 = lane & 15, kq = lane >> 4;
     const int c_nh = (wave >> 1) & 1, c_sub = (wave & 1) + 2 * (wave >> 2), c_ch = c_nh * 16 + j16;
     const bool c_chv = c_ch < OD;
     constexpr int NPD = (G::RBB * OD * 25 + kBlock - 1) / kBlock, NPI = (G::RBB * 243 + kBlock - 1) / kBlock;
-    float pfd[RC ? NPD : 1], pfi[RC ? NPI : 1];
+    float pfd[NPD], pfi[NPI];
     auto fetch = [&](long b) {
         const long r0 = b * G::RBB;
         const int rvb = b < blk1 ? (int)min((long)G::RBB, rows - r0) : 0;
@@ -254,88 +124,70 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
             pfi[u] = (i < G::RBB * 243 && rr < rvb) ? (float)obs[(r0 + rr) * obs_stride + pp] : 0.0f;
         }
     };
-    if constexpr (RC) fetch(blk0);
+    fetch(blk0);
     for (long blk = blk0; blk < blk1; ++blk) {
         const long row0 = blk * G::RBB;
         const int rv = (int)min((long)G::RBB, rows - row0);
         __syncthreads();
-        if constexpr (RC) {
-            // ---- P0 (RC): park the prefetched rows, then conv1 + ReLU on MFMA into s_a1 ([row][c][52])
-            int t_ = tid;
-            asm volatile("" : "+v"(t_));
+        // ---- P0: park the prefetched rows, then conv1 + ReLU on MFMA into s_a1 ([row][c][52])
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
 #pragma unroll
-            for (int u = 0; u < NPD; ++u) {
-                const int i = t_ + u * kBlock, rc = i / 25, k = i - rc * 25;
-                if (i < G::RBB * OD * 25) s_dz2[(rc / OD) * G::DZ_ROW + (rc % OD) * G::DZ2 + k] = pfd[u];
-            }
+        for (int u = 0; u < NPD; ++u) {
+            const int i = t_ + u * kBlock, rc = i / 25, k = i - rc * 25;
+            if (i < G::RBB * OD * 25) s_dz2[(rc / OD) * G::DZ_ROW + (rc % OD) * G::DZ2 + k] = pfd[u];
+        }
 #pragma unroll
-            for (int u = 0; u < NPI; ++u) {
-                const int i = t_ + u * kBlock, rr = i / 243, pp = i - rr * 243;
-                if (i < G::RBB * 243) s_in[rr * 244 + pp] = pfi[u];
-            }
-            __syncthreads();
-            // the conv1 B operands are re-read from L2 every block: nothing of this phase stays in registers
-            // while the gradient phases run at the register limit
-            int off1[7], goff[3];
-            float bw1[7];
-            int kq_ = kq, j_ = j16;
-            asm volatile("" : "+v"(kq_), "+v"(j_));
+        for (int u = 0; u < NPI; ++u) {
+            const int i = t_ + u * kBlock, rr = i / 243, pp = i - rr * 243;
+            if (i < G::RBB * 243) s_in[rr * 244 + pp] = pfi[u];
+        }
+        __syncthreads();
+        // the conv1 B operands are re-read from L2 every block: nothing of this phase stays in registers
+        // while the gradient phases run at the register limit
+        int off1[7], goff[3];
+        float bw1[7];
+        int kq_ = kq, j_ = j16;
+        asm volatile("" : "+v"(kq_), "+v"(j_));
 #pragma unroll
-            for (int s = 0; s < 7; ++s) {
-                const int k = 4 * s + kq_, c0 = k / 9, tap = k - c0 * 9;
-                off1[s] = k < 27 ? c0 * 81 + (tap / 3) * 9 + tap % 3 : 0;
-                bw1[s] = (c_chv && k < 27) ? w1[c_ch * 27 + k] : 0.0f;
-            }
-            const float c_bias = c_chv ? b1[c_ch] : 0.0f;
+        for (int s = 0; s < 7; ++s) {
+            const int k = 4 * s + kq_, c0 = k / 9, tap = k - c0 * 9;
+            off1[s] = k < 27 ? c0 * 81 + (tap / 3) * 9 + tap % 3 : 0;
+            bw1[s] = (c_chv && k < 27) ? w1[c_ch * 27 + k] : 0.0f;
+        }
+        const float c_bias = c_chv ? b1[c_ch] : 0.0f;
 #pragma unroll
-            for (int qt = 0; qt < 3; ++qt) { const int p = qt * 16 + j_; goff[qt] = (p / 7) * 9 + p % 7; }
-            for (int rr = c_sub; rr < G::RBB; rr += 4) {
-                float cv[3][7];
+        for (int qt = 0; qt < 3; ++qt) { const int p = qt * 16 + j_; goff[qt] = (p / 7) * 9 + p % 7; }
+        for (int rr = c_sub; rr < G::RBB; rr += 4) {
+            float cv[3][7];
+#pragma unroll
+            for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+                for (int s = 0; s < 7; ++s) cv[qt][s] = s_in[rr * 244 + goff[qt] + off1[s]];
+            f32x4 acc[3];
+#pragma unroll
+            for (int qt = 0; qt < 3; ++qt) acc[qt] = f32x4{c_bias, c_bias, c_bias, c_bias};
+#pragma unroll
+            for (int s = 0; s < 7; ++s)
+#pragma unroll
+                for (int qt = 0; qt < 3; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[qt][s], bw1[s], acc[qt], 0, 0, 0);
+            if (c_chv) {
+                float *dst = s_a1 + (rr * OD + c_ch) * kA1Stride + kq * 4;
 #pragma unroll
                 for (int qt = 0; qt < 3; ++qt)
 #pragma unroll
-                    for (int s = 0; s < 7; ++s) cv[qt][s] = s_in[rr * 244 + goff[qt] + off1[s]];
-                f32x4 acc[3];
-#pragma unroll
-                for (int qt = 0; qt < 3; ++qt) acc[qt] = f32x4{c_bias, c_bias, c_bias, c_bias};
-#pragma unroll
-                for (int s = 0; s < 7; ++s)
-#pragma unroll
-                    for (int qt = 0; qt < 3; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[qt][s], bw1[s], acc[qt], 0, 0, 0);
-                if (c_chv) {
-                    float *dst = s_a1 + (rr * OD + c_ch) * kA1Stride + kq * 4;
-#pragma unroll
-                    for (int qt = 0; qt < 3; ++qt)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) dst[qt * 16 + q] = fmaxf(acc[qt][q], 0.0f);
-                }
+                    for (int q = 0; q < 4; ++q) dst[qt * 16 + q] = fmaxf(acc[qt][q], 0.0f);
             }
-            if (c_sub == 0) {  // position 48 of every row: lane i gathers row i
-                const int rr = j16 < G::RBB ? j16 : G::RBB - 1;
-                f32x4 acc = {c_bias, c_bias, c_bias, c_bias};
+        }
+        if (c_sub == 0) {  // position 48 of every row: lane i gathers row i
+            const int rr = j16 < G::RBB ? j16 : G::RBB - 1;
+            f32x4 acc = {c_bias, c_bias, c_bias, c_bias};
 #pragma unroll
-                for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s_in[rr * 244 + 60 + off1[s]], bw1[s], acc, 0, 0, 0);
-                if (c_chv) {
+            for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s_in[rr * 244 + 60 + off1[s]], bw1[s], acc, 0, 0, 0);
+            if (c_chv) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (kq * 4 + q < G::RBB) s_a1[((kq * 4 + q) * OD + c_ch) * kA1Stride + 48] = fmaxf(acc[q], 0.0f);
-                }
-            }
-        } else {
-            // ---- P0: stage the rows (a1 is saved in the padded LDS layout: straight 16-byte copies)
-            {
-                const float4 *src = (const float4 *)(a1_save + row0 * OD * kA1Stride);
-                float4 *dst = (float4 *)s_a1;
-                for (int i = tid; i < rv * OD * kA1Stride / 4; i += kBlock) dst[i] = src[i];
-            }
-            for (int i = tid; i < rv * OD * 25; i += kBlock) {
-                const int rr = i / (OD * 25), rem = i - rr * OD * 25, c = rem / 25, k = rem - c * 25;
-                const float act = a2[(row0 + rr) * a2_stride + rem];
-                s_dz2[rr * G::DZ_ROW + c * G::DZ2 + k] = act > 0.0f ? g[(row0 + rr) * g_stride + rem] : 0.0f;
-            }
-            for (int i = tid; i < rv * 243; i += kBlock) {
-                const int rr = i / 243, pp = i - rr * 243;
-                s_in[rr * 244 + pp] = (float)obs[(row0 + rr) * obs_stride + pp];
+                for (int q = 0; q < 4; ++q)
+                    if (kq * 4 + q < G::RBB) s_a1[((kq * 4 + q) * OD + c_ch) * kA1Stride + 48] = fmaxf(acc[q], 0.0f);
             }
         }
         __syncthreads();
@@ -414,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
             for (int k = 0; k < 49; ++k) dst[k] = act[k] > 0.0f ? da[k] + dst[k] : 0.0f;
         }
         __syncthreads();
-        if constexpr (RC) fetch(blk + 1);  // lands while P3 runs; parked after the next barrier
+        fetch(blk + 1);  // lands while P3 runs; parked after the next barrier
         // ---- P3: dW1[c1][c0][kx][0..2] over this thread's row slice (and db1)
 #ifdef CRNN_PROBE_SKIP_P3
         if (false) {
@@ -519,11 +371,6 @@ __global__ __launch_bounds__(64 * kRedY) void k_conv9_bwd_reduce(const float *__
 
 thread_local int g_last_hip = 0;
 
-bool use_valu_conv() {  // CRNN_CONV_IMPL=valu selects the f32 VALU kernel (k_conv9); default: the f32 MFMA kernel
-    static const bool v = [] { const char *e = getenv("CRNN_CONV_IMPL"); return e && e[0] == 'v'; }();
-    return v;
-}
-
 // The dynamic-LDS limit is an attribute of the function ON ONE DEVICE: remember per device whether it has been raised
 // (a process may drive several GPUs; one rank per GPU is the normal case).  Thread-compatible like the rest of the ABI.
 struct PerDeviceOnce {
@@ -544,77 +391,43 @@ struct PerDeviceOnce {
 };
 
 template <int OD>
-int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w2,
-           const float *b2, float *out, long out_stride, const int8_t *onehot, int n_actions, const float *mlp_w,
-           const float *mlp_b, float *a1_save, hipStream_t s) {
-    using G = Geo<OD>;
+int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w2, const float *b2,
+           float *out, long out_stride, const int8_t *onehot, int n_actions, const float *mlp_w, const float *mlp_b, hipStream_t s) {
     using GM = crnn_mfma::GeoM<OD>;
-    const bool valu = use_valu_conv();
-    const size_t lds = (valu ? G::LDS_FLOATS : GM::LDS_FLOATS) * sizeof(float);
+    const size_t lds = GM::LDS_FLOATS * sizeof(float);
     static PerDeviceOnce attr_set;
     if (attr_set.need()) {
-        hipError_t e = valu ? hipFuncSetAttribute((const void *)k_conv9<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                            : hipFuncSetAttribute((const void *)crnn_mfma::k_conv9_mfma<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)crnn_mfma::k_conv9_mfma<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
         attr_set.mark();
     }
-    const int rb = valu ? G::RB : GM::RB;
-    const long n_blocks = (rows + rb - 1) / rb;
+    const long n_blocks = (rows + GM::RB - 1) / GM::RB;
     const int grid = (int)(n_blocks < 256 ? n_blocks : 256);  // persistent: one workgroup per CU keeps the weights resident
     (void)hipGetLastError();
-    if (valu)
-        hipLaunchKernelGGL((k_conv9<OD>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, w1, b1, w2, b2, out, out_stride, onehot,
-                           n_actions, mlp_w, mlp_b, a1_save);
-    else
-        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, s, obs, obs_stride, rows, w1, b1, w2, b2,
-                           out, out_stride, onehot, n_actions, mlp_w, mlp_b, a1_save);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        g_last_hip = (int)e;
-        if (getenv("DMFB_VEC_DEBUG")) fprintf(stderr, "crnn_ops: launch failed: %s\n", hipGetErrorString(e));
-        return CRNN_ERR_HIP;
-    }
-    return CRNN_OK;
-}
-
-
-template <int OD, bool RC>
-int launch_bwd(const int8_t *obs, long obs_stride, long rows, const float *a1_save, const float *a2, long a2_stride,
-               const float *g, long g_stride, const float *w2, float *part, int grid, float *grads, const float *w1, const float *b1,
-               hipStream_t s) {
-    using G = GeoB<OD>;
-    const size_t lds = G::LDS_FLOATS * sizeof(float);
-    static PerDeviceOnce attr_set;
-    if (attr_set.need()) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv9_bwd<OD, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
-        attr_set.mark();
-    }
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((k_conv9_bwd<OD, RC>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, a1_save, a2, a2_stride, g, g_stride,
-                       w2, part, w1, b1);
-    const int n_out = OD * OD * 9 + OD + OD * 27 + OD;
-    hipLaunchKernelGGL((k_conv9_bwd_reduce<OD>), dim3((n_out + 63) / 64), dim3(64 * kRedY), 0, s, part, grid, grads);
+    hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, s, obs, obs_stride, rows, w1, b1, w2, b2,
+                       out, out_stride, onehot, n_actions, mlp_w, mlp_b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
     return CRNN_OK;
 }
 
 template <int OD>
-int launch_bwd_mfma(const int8_t *obs, long obs_stride, long rows, const float *a2, long a2_stride, const float *g, long g_stride,
-                    const float *w1, const float *b1, const float *w2, float *part, int grid, float *grads, hipStream_t s) {
-    using G = crnn_mfma::GeoMB<OD>;
+int launch_bwd(const int8_t *obs, long obs_stride, long rows, const float *a2, long a2_stride,
+               const float *g, long g_stride, const float *w2, float *part, int grid, float *grads, const float *w1, const float *b1,
+               hipStream_t s) {
+    using G = GeoB<OD>;
     const size_t lds = G::LDS_FLOATS * sizeof(float);
     static PerDeviceOnce attr_set;
     if (attr_set.need()) {
-        hipError_t e = hipFuncSetAttribute((const void *)crnn_mfma::k_conv9_bwd_mfma<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv9_bwd<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
         attr_set.mark();
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL((crnn_mfma::k_conv9_bwd_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockB), lds, s, obs, obs_stride, rows, a2, a2_stride, g,
-                       g_stride, w1, b1, w2, part);
-    hipLaunchKernelGGL((crnn_mfma::k_conv9_bwd_mfma_reduce<OD>), dim3((G::PART + 255) / 256), dim3(256), 0, s, part, grid, grads);
+    hipLaunchKernelGGL((k_conv9_bwd<OD>), dim3(grid), dim3(kBlock), lds, s, obs, obs_stride, rows, a2, a2_stride, g, g_stride,
+                       w2, part, w1, b1);
+    const int n_out = OD * OD * 9 + OD + OD * 27 + OD;
+    hipLaunchKernelGGL((k_conv9_bwd_reduce<OD>), dim3((n_out + 63) / 64), dim3(64 * kRedY), 0, s, part, grid, grads);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
     return CRNN_OK;
@@ -629,8 +442,8 @@ int crnn_conv9_forward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, co
     if (!d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_out || rows < 0 || obs_stride < 243 || out_stride < od * 25)
         return CRNN_ERR_BAD_ARG;
     if (rows == 0) return CRNN_OK;
-    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
-    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
 }
 
@@ -641,70 +454,20 @@ int crnn_front9_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d
         out_stride < od * 25 + 10 || n_actions < 0 || n_actions > 16)
         return CRNN_ERR_BAD_ARG;
     if (rows == 0) return CRNN_OK;
-    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, nullptr, (hipStream_t)stream);
-    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, nullptr, (hipStream_t)stream);
-    return CRNN_ERR_UNSUPPORTED;
-}
-
-int crnn_conv9_forward_train(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_w1, const float *d_b1,
-                             const float *d_w2, const float *d_b2, int od, float *d_out, int64_t out_stride, float *d_a1_save,
-                             void *stream) {
-    if (!d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_out || !d_a1_save || rows < 0 || obs_stride < 243 || out_stride < od * 25)
-        return CRNN_ERR_BAD_ARG;
-    if (rows == 0) return CRNN_OK;
-    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, d_a1_save, (hipStream_t)stream);
-    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, d_a1_save, (hipStream_t)stream);
-    return CRNN_ERR_UNSUPPORTED;
-}
-
-int crnn_front9_forward_train(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
-                              const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
-                              const float *d_mlp_b, int od, float *d_out, int64_t out_stride, float *d_a1_save, void *stream) {
-    if (!d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_mlp_w || !d_mlp_b || !d_out || !d_a1_save || rows < 0 || obs_stride < 245 ||
-        out_stride < od * 25 + 10 || n_actions < 0 || n_actions > 16)
-        return CRNN_ERR_BAD_ARG;
-    if (rows == 0) return CRNN_OK;
-    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, d_a1_save, (hipStream_t)stream);
-    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, d_a1_save, (hipStream_t)stream);
+    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
+    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
 }
 
 int crnn_conv9_backward_parts(int od) { return od == 24 ? GeoB<24>::PART : od == 32 ? GeoB<32>::PART : CRNN_ERR_UNSUPPORTED; }
-int crnn_conv9_a1_floats(int od) { return od * kA1Stride; }
 
-int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_a1_save, const float *d_out,
-                        int64_t out_stride, const float *d_grad_out, int64_t grad_stride, const float *d_w2, int od,
-                        float *d_part, int n_part, float *d_grads, void *stream) {
-    if (!d_obs || !d_a1_save || !d_out || !d_grad_out || !d_w2 || !d_part || !d_grads || rows <= 0 || n_part < 1 || n_part > 256)
+int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
+                        const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1, const float *d_w2,
+                        int od, float *d_part, int n_part, float *d_grads, void *stream) {
+    if (!d_obs || !d_out || !d_grad_out || !d_w1 || !d_b1 || !d_w2 || !d_part || !d_grads || rows <= 0 || n_part < 1 || n_part > 256)
         return CRNN_ERR_BAD_ARG;
-    if (od == 24) return launch_bwd<24, false>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, nullptr, nullptr, (hipStream_t)stream);
-    if (od == 32) return launch_bwd<32, false>(d_obs, obs_stride, rows, d_a1_save, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, nullptr, nullptr, (hipStream_t)stream);
-    return CRNN_ERR_UNSUPPORTED;
-}
-
-int crnn_conv9_backward_rc(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
-                           const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1, const float *d_w2,
-                           int od, float *d_part, int n_part, float *d_grads, void *stream) {
-    if (!d_obs || !d_out || !d_grad_out || !d_w1 || !d_b1 || !d_w2 || !d_part || !d_grads || rows <= 0 || n_part < 1 || n_part > 256 ||
-        obs_stride < 243 || out_stride < od * 25 || grad_stride < od * 25)
-        return CRNN_ERR_BAD_ARG;
-    if (od == 24) return launch_bwd<24, true>(d_obs, obs_stride, rows, nullptr, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, d_w1, d_b1, (hipStream_t)stream);
-    if (od == 32) return launch_bwd<32, true>(d_obs, obs_stride, rows, nullptr, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, d_w1, d_b1, (hipStream_t)stream);
-    return CRNN_ERR_UNSUPPORTED;
-}
-
-int crnn_conv9_backward_mfma_parts(int od) {
-    return od == 24 ? crnn_mfma::GeoMB<24>::PART : od == 32 ? crnn_mfma::GeoMB<32>::PART : CRNN_ERR_UNSUPPORTED;
-}
-
-int crnn_conv9_backward_mfma(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
-                             const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1,
-                             const float *d_w2, int od, float *d_part, int n_part, float *d_grads, void *stream) {
-    if (!d_obs || !d_out || !d_grad_out || !d_w1 || !d_b1 || !d_w2 || !d_part || !d_grads || rows <= 0 || n_part < 1 || n_part > 256 ||
-        obs_stride < 243 || out_stride < od * 25 || grad_stride < od * 25)
-        return CRNN_ERR_BAD_ARG;
-    if (od == 24) return launch_bwd_mfma<24>(d_obs, obs_stride, rows, d_out, out_stride, d_grad_out, grad_stride, d_w1, d_b1, d_w2, d_part, n_part, d_grads, (hipStream_t)stream);
-    if (od == 32) return launch_bwd_mfma<32>(d_obs, obs_stride, rows, d_out, out_stride, d_grad_out, grad_stride, d_w1, d_b1, d_w2, d_part, n_part, d_grads, (hipStream_t)stream);
+    if (od == 24) return launch_bwd<24>(d_obs, obs_stride, rows, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, d_w1, d_b1, (hipStream_t)stream);
+    if (od == 32) return launch_bwd<32>(d_obs, obs_stride, rows, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, d_w1, d_b1, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
 }
 

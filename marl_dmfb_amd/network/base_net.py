@@ -44,76 +44,66 @@ class _ConvGemm(torch.autograd.Function):
         return gcols, gw, g.sum(0)
 
 
+N_PART = 256  # partial gradient vectors of the conv backward kernel (one per persistent workgroup)
+
+
+def _conv9_backward(obs_i8, x, g, w1c, b1c, w2c, od):
+    """include/crnn_ops.h: crnn_conv9_backward -> flat dW2 | db2 | dW1 | db1."""
+    import ctypes as C
+    from .. import _lib
+    lib = _lib.crnn_ops()
+    vp = C.c_void_p
+    if g.stride(1) != 1:
+        g = g.contiguous()
+    R = obs_i8.shape[0]
+    tot = torch.empty(od * od * 9 + od + od * 27 + od, dtype=torch.float32, device=g.device)
+    part = torch.empty((N_PART, lib.crnn_conv9_backward_parts(od)), dtype=torch.float32, device=g.device)
+    rc = lib.crnn_conv9_backward(vp(obs_i8.data_ptr()), obs_i8.stride(0), R, vp(x.data_ptr()), x.stride(0), vp(g.data_ptr()),
+                                 g.stride(0), vp(w1c.data_ptr()), vp(b1c.data_ptr()), vp(w2c.data_ptr()), od, vp(part.data_ptr()),
+                                 N_PART, vp(tot.data_ptr()), vp(torch.cuda.current_stream(g.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError('crnn_conv9_backward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
+    return tot
+
+
 class _ConvFront9(torch.autograd.Function):
     """conv1+ReLU+conv2+ReLU of int8 observation rows for fov 9 through the hand-written HIP kernels
-    (include/crnn_ops.h: crnn_conv9_forward_train / crnn_conv9_backward), with gradients for the four
-    parameter tensors.  Used for the eval network inside VDN.learn on the GPU."""
-
-    N_PART = 256
+    (include/crnn_ops.h: crnn_conv9_forward / crnn_conv9_backward), with gradients for the four parameter tensors.
+    Used for the eval network inside VDN.learn on the GPU when the vector branch cannot be fused (see _Front9Train)."""
 
     @staticmethod
     def forward(ctx, obs_i8, w1, b1, w2, b2):
         import ctypes as C
         from .. import _lib
         lib = _lib.crnn_ops()
+        vp = C.c_void_p
         obs_i8 = obs_i8.contiguous()
         R, od = obs_i8.shape[0], w1.shape[0]
         out = torch.empty((R, od * 25), dtype=torch.float32, device=obs_i8.device)
-        a1 = torch.empty((R, lib.crnn_conv9_a1_floats(od)), dtype=torch.float32, device=obs_i8.device)
-        w1c, b1c, w2c, b2c = w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
-        stream = C.c_void_p(torch.cuda.current_stream(obs_i8.device).cuda_stream)
-        rc = lib.crnn_conv9_forward_train(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), R, C.c_void_p(w1c.data_ptr()),
-                                          C.c_void_p(b1c.data_ptr()), C.c_void_p(w2c.data_ptr()), C.c_void_p(b2c.data_ptr()),
-                                          od, C.c_void_p(out.data_ptr()), out.stride(0), C.c_void_p(a1.data_ptr()), stream)
+        w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
+        rc = lib.crnn_conv9_forward(vp(obs_i8.data_ptr()), obs_i8.stride(0), R, vp(w1c.data_ptr()), vp(b1c.data_ptr()),
+                                    vp(w2c.data_ptr()), vp(b2c.data_ptr()), od, vp(out.data_ptr()), out.stride(0),
+                                    vp(torch.cuda.current_stream(obs_i8.device).cuda_stream))
         if rc != 0:
-            raise RuntimeError('crnn_conv9_forward_train failed: %d' % rc)
-        ctx.save_for_backward(obs_i8, a1, out, w2c)
+            raise RuntimeError('crnn_conv9_forward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
+        ctx.save_for_backward(obs_i8, out, w1c, b1c, w2c)   # nothing extra is saved: the backward recomputes conv1
         ctx.shapes = (w1.shape, w2.shape)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        import ctypes as C
-        from .. import _lib
-        lib = _lib.crnn_ops()
-        obs_i8, a1, out, w2c = ctx.saved_tensors
+        obs_i8, out, w1c, b1c, w2c = ctx.saved_tensors
         (s1, s2) = ctx.shapes
-        od, R = s1[0], obs_i8.shape[0]
-        g = g.contiguous()
-        plen = lib.crnn_conv9_backward_parts(od)
-        part = torch.empty((_ConvFront9.N_PART, plen), dtype=torch.float32, device=g.device)
+        od = s1[0]
         n2 = od * od * 9
-        tot = torch.empty(n2 + od + od * 27 + od, dtype=torch.float32, device=g.device)
-        stream = C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
-        rc = lib.crnn_conv9_backward(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), R, C.c_void_p(a1.data_ptr()),
-                                     C.c_void_p(out.data_ptr()), out.stride(0), C.c_void_p(g.data_ptr()), g.stride(0),
-                                     C.c_void_p(w2c.data_ptr()), od, C.c_void_p(part.data_ptr()), _ConvFront9.N_PART,
-                                     C.c_void_p(tot.data_ptr()), stream)
-        if rc != 0:
-            raise RuntimeError('crnn_conv9_backward failed: %d' % rc)
-        g_w2 = tot[:n2].view(s2)
-        g_b2 = tot[n2:n2 + od]
-        g_w1 = tot[n2 + od:n2 + od + od * 27].view(s1)
-        g_b1 = tot[n2 + od + od * 27:]
-        return None, g_w1, g_b1, g_w2, g_b2
-
-
-def _conv_bwd_mode():
-    """Backward kernel of the conv front end, CRNN_CONV_BWD = rc | valu | mfma:
-    rc (default)  VALU gradient kernel that recomputes conv1 on the matrix cores and prefetches the next row block
-                  (crnn_conv9_backward_rc); the forward saves nothing;
-    valu          the same kernel reading the conv1 activations saved by crnn_front9_forward_train;
-    mfma          all three contractions on MFMA (csrc/crnn_mfma_bwd.h; correct, but its col2im phase scatters through
-                  LDS float atomics: 3.2 ms per 81920 rows vs 1.6 ms for valu on MI355X)."""
-    import os
-    m = os.environ.get('CRNN_CONV_BWD', 'rc')
-    return m if m in ('rc', 'valu', 'mfma') else 'rc'
+        tot = _conv9_backward(obs_i8, out, g, w1c, b1c, w2c, od)
+        return None, tot[n2 + od:n2 + od + od * 27].view(s1), tot[n2 + od + od * 27:], tot[:n2].view(s2), tot[n2:n2 + od]
 
 
 class _Front9Train(torch.autograd.Function):
     """The whole GRU input row x = cat([conv features, relu(mlp1([dir, last action]))]) of the eval network in ONE
-    launch (crnn_front9_forward[_train]) with a hand-written backward: crnn_conv9_backward[_mfma] for the four conv
-    tensors (reading the row-strided gradient in place) and two small split-K GEMMs for mlp1."""
+    launch (crnn_front9_forward) with a hand-written backward: crnn_conv9_backward for the four conv tensors (reading
+    the row-strided gradient in place, recomputing conv1) and two small split-K GEMMs for mlp1."""
 
     @staticmethod
     def forward(ctx, obs_i8, onehot_i8, w1, b1, w2, b2, mlp_w, mlp_b):
@@ -125,58 +115,23 @@ class _Front9Train(torch.autograd.Function):
         R, od, A = obs_i8.shape[0], w1.shape[0], onehot_i8.shape[1]
         x = torch.empty((R, od * 25 + 10), dtype=torch.float32, device=obs_i8.device)
         w1c, b1c, w2c, b2c, mwc, mbc = (t.detach().contiguous() for t in (w1, b1, w2, b2, mlp_w, mlp_b))
-        stream = vp(torch.cuda.current_stream(obs_i8.device).cuda_stream)
-        ctx.mode = _conv_bwd_mode()
-        if ctx.mode != 'valu':
-            a1 = w1c  # placeholder: nothing is saved, the backward recomputes conv1
-            rc = lib.crnn_front9_forward(vp(obs_i8.data_ptr()), obs_i8.stride(0), vp(onehot_i8.data_ptr()), A, R, vp(w1c.data_ptr()),
-                                         vp(b1c.data_ptr()), vp(w2c.data_ptr()), vp(b2c.data_ptr()), vp(mwc.data_ptr()),
-                                         vp(mbc.data_ptr()), od, vp(x.data_ptr()), x.stride(0), stream)
-        else:
-            a1 = torch.empty((R, lib.crnn_conv9_a1_floats(od)), dtype=torch.float32, device=obs_i8.device)
-            rc = lib.crnn_front9_forward_train(vp(obs_i8.data_ptr()), obs_i8.stride(0), vp(onehot_i8.data_ptr()), A, R,
-                                               vp(w1c.data_ptr()), vp(b1c.data_ptr()), vp(w2c.data_ptr()), vp(b2c.data_ptr()),
-                                               vp(mwc.data_ptr()), vp(mbc.data_ptr()), od, vp(x.data_ptr()), x.stride(0),
-                                               vp(a1.data_ptr()), stream)
+        rc = lib.crnn_front9_forward(vp(obs_i8.data_ptr()), obs_i8.stride(0), vp(onehot_i8.data_ptr()), A, R, vp(w1c.data_ptr()),
+                                     vp(b1c.data_ptr()), vp(w2c.data_ptr()), vp(b2c.data_ptr()), vp(mwc.data_ptr()),
+                                     vp(mbc.data_ptr()), od, vp(x.data_ptr()), x.stride(0),
+                                     vp(torch.cuda.current_stream(obs_i8.device).cuda_stream))
         if rc != 0:
             raise RuntimeError('crnn_front9_forward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
-        ctx.save_for_backward(obs_i8, onehot_i8, a1, x, w1c, b1c, w2c)
+        ctx.save_for_backward(obs_i8, onehot_i8, x, w1c, b1c, w2c)
         ctx.shapes = (w1.shape, w2.shape)
         return x
 
     @staticmethod
     def backward(ctx, g):
-        import ctypes as C
-        from .. import _lib
-        lib = _lib.crnn_ops()
-        vp = C.c_void_p
-        obs_i8, onehot_i8, a1, x, w1c, b1c, w2c = ctx.saved_tensors
+        obs_i8, onehot_i8, x, w1c, b1c, w2c = ctx.saved_tensors
         (s1, s2) = ctx.shapes
-        od, R = s1[0], obs_i8.shape[0]
-        if g.stride(1) != 1:
-            g = g.contiguous()
+        od = s1[0]
         n2 = od * od * 9
-        tot = torch.empty(n2 + od + od * 27 + od, dtype=torch.float32, device=g.device)
-        stream = vp(torch.cuda.current_stream(g.device).cuda_stream)
-        if ctx.mode == 'rc':
-            part = torch.empty((_ConvFront9.N_PART, lib.crnn_conv9_backward_parts(od)), dtype=torch.float32, device=g.device)
-            rc = lib.crnn_conv9_backward_rc(vp(obs_i8.data_ptr()), obs_i8.stride(0), R, vp(x.data_ptr()), x.stride(0),
-                                            vp(g.data_ptr()), g.stride(0), vp(w1c.data_ptr()), vp(b1c.data_ptr()),
-                                            vp(w2c.data_ptr()), od, vp(part.data_ptr()), _ConvFront9.N_PART, vp(tot.data_ptr()),
-                                            stream)
-        elif ctx.mode == 'mfma':
-            part = torch.empty((_ConvFront9.N_PART, lib.crnn_conv9_backward_mfma_parts(od)), dtype=torch.float32, device=g.device)
-            rc = lib.crnn_conv9_backward_mfma(vp(obs_i8.data_ptr()), obs_i8.stride(0), R, vp(x.data_ptr()), x.stride(0),
-                                              vp(g.data_ptr()), g.stride(0), vp(w1c.data_ptr()), vp(b1c.data_ptr()),
-                                              vp(w2c.data_ptr()), od, vp(part.data_ptr()), _ConvFront9.N_PART, vp(tot.data_ptr()),
-                                              stream)
-        else:
-            part = torch.empty((_ConvFront9.N_PART, lib.crnn_conv9_backward_parts(od)), dtype=torch.float32, device=g.device)
-            rc = lib.crnn_conv9_backward(vp(obs_i8.data_ptr()), obs_i8.stride(0), R, vp(a1.data_ptr()), vp(x.data_ptr()), x.stride(0),
-                                         vp(g.data_ptr()), g.stride(0), vp(w2c.data_ptr()), od, vp(part.data_ptr()),
-                                         _ConvFront9.N_PART, vp(tot.data_ptr()), stream)
-        if rc != 0:
-            raise RuntimeError('crnn_conv9_backward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
+        tot = _conv9_backward(obs_i8, x, g, w1c, b1c, w2c, od)
         gz = g[:, od * 25:] * (x[:, od * 25:] > 0)
         vec = torch.cat([obs_i8[:, 243:245].float(), onehot_i8.float()], dim=1)
         g_mw = _wgrad_splitk(gz.contiguous(), vec)

@@ -69,7 +69,7 @@ def test_forward_obs_uses_kernel_and_matches_reference_forward():
 
 @pytest.mark.parametrize('od,rows', [(24, 20000), (32, 5003), (24, 11)])
 def test_conv9_training_pair_matches_torch_autograd(od, rows):
-    """Forward (saving activations) + backward kernels against torch autograd on conv2d (float64 reference)."""
+    """Forward + backward kernels (_ConvFront9) against torch autograd on conv2d (float64 reference)."""
     from marl_dmfb_amd.network.base_net import CRNN, _ConvFront9
     a = types.SimpleNamespace(obs_shape=(3, 9, 9, 2, 245), hyper_hidden_dim=od, rnn_hidden_dim=128, n_actions=5, fov=9)
     torch.manual_seed(od * 7 + rows)
@@ -156,14 +156,12 @@ def test_recurrent_seq_hip_equals_aten_path():
         assert torch.linalg.norm(g1 - g2) <= 1e-4 * torch.linalg.norm(g2)
 
 
-@pytest.mark.parametrize('bwd', ['rc', 'valu', 'mfma'])
 @pytest.mark.parametrize('od,rows', [(24, 20000), (32, 5003), (24, 11), (24, 8), (24, 2563)])
-def test_front9_train_node_matches_torch_autograd(od, rows, bwd, monkeypatch):
-    """_Front9Train (fused forward incl. mlp1; VALU backward on saved activations, or the MFMA backward that recomputes
-    conv1) against float64 torch autograd of the reference network's front end (network/base_net.py:59-68); rows with a
+def test_front9_train_node_matches_torch_autograd(od, rows):
+    """_Front9Train (fused forward incl. mlp1; backward kernel that recomputes conv1 on the matrix cores) against float64
+    torch autograd of the reference network's front end (network/base_net.py:59-68); rows with a
     knife-edge ReLU get a zero upstream gradient (_safe_rows), tolerance GRAD_TOL."""
     from marl_dmfb_amd.network.base_net import CRNN, _Front9Train
-    monkeypatch.setenv('CRNN_CONV_BWD', bwd)
     a = types.SimpleNamespace(obs_shape=(3, 9, 9, 2, 245), hyper_hidden_dim=od, rnn_hidden_dim=128, n_actions=5, fov=9)
     torch.manual_seed(od * 11 + rows)
     net = CRNN(a).cuda()
@@ -187,5 +185,5 @@ def test_front9_train_node_matches_torch_autograd(od, rows, bwd, monkeypatch):
     for name, g, r in zip(('w1', 'b1', 'w2', 'b2', 'mlp_w', 'mlp_b'), got,
                           (r1.weight.grad, r1.bias.grad, r2.weight.grad, r2.bias.grad, ref.mlp1.weight.grad, ref.mlp1.bias.grad)):
         err = _rel_l2(g.numpy(), r.numpy())
-        print('front9 %s od=%d rows=%d %s rel_l2=%.2e' % (bwd, od, rows, name, err))
+        print('front9 od=%d rows=%d %s rel_l2=%.2e' % (od, rows, name, err))
         assert err <= GRAD_TOL, (name, err)
