@@ -51,6 +51,8 @@ struct DevCfg {
     int nq;              // 8-byte words per band image, padded to a multiple of 12 (see DevPtrs::band)
     int ucap;            // steps a chip's usage log holds (= max_step), see DevPtrs::ulog
     int hist_bytes;      // LDS bytes of one wave's usage histogram, 0 = chip too large for LDS (global-atomic path)
+    int compact;         // 1: the maps are the generator's own (never replaced through set_map): the transition may rebuild a
+                         // cell's health from DevPtrs::kmap instead of gathering the float64 map (see health_of)
     double per_healthy;
 };
 
@@ -65,6 +67,11 @@ struct DevPtrs {
     // contiguous bytes instead of n read-modify-writes scattered over a 64/128-byte sector each; the log is folded into the
     // usage map (flush_usage) when the episode is reset, when it is full, and before the map is read or written from outside.
     uint16_t *ulog;
+    // How often updateHealth (dmfb.py:465-471) has degraded each cell since the maps were generated, saturating at 255:
+    // uint8 [E][W*L].  m_health[cell] is then 1.0 multiplied `k` times by m_degrade[cell] -- the very products the reference
+    // forms -- and m_degrade[cell] is a pure function of the Philox key (gen_degrade_env), so a transition can read one
+    // BYTE per droplet (a chip's whole map is a few 128-byte lines) instead of one float64 from a 128-byte line each.
+    uint8_t *kmap;
     const int8_t *zoom;  // [2][511] direction zoom table
     uint32_t *blocks;    // [n_blocks][E] x_min | x_max<<8 | y_min<<16 | y_max<<24, or nullptr
     // Observation tables, copied into LDS by every workgroup that builds observations (table_words() 8-byte words):
@@ -301,20 +308,26 @@ __device__ __forceinline__ void update_health_env(const DevPtrs &p, int cells, i
         }
     }
 }
+// m_degrade of one cell (the value gen_degrade_env stores) and m_health rebuilt from the degrade count
+__device__ __forceinline__ double degrade_of(const DevCfg &c, uint32_t env_gid, uint32_t rmap, int cell) {
+    if (!c.b_degrade) return 1.0;
+    uint32_t w[4];
+    philox(c.k0, c.k1, env_gid, rmap, (uint32_t)cell, STREAM_DEGRADE << 8, w);
+    const double d = u53(w[0], w[1]) * 0.4 + 0.6;
+    return (u53(w[2], w[3]) < c.per_healthy) ? 1.0 : d;
+}
+__device__ __forceinline__ double health_from_count(double d, int k) {
+    double h = 1.0;
+    for (int t = 0; t < k; ++t) h = h * d;  // the reference's products, in its order (dmfb.py:469)
+    return h;
+}
+
 // _random_health_statue (dmfb.py:157-166) for one env
 __device__ __forceinline__ void gen_degrade_env(const DevCfg &c, const DevPtrs &p, int cells, int e, uint32_t rmap,
                                                 int tid, int nthreads) {
     const size_t base = (size_t)e * cells;
     for (int cidx = tid; cidx < cells; cidx += nthreads) {
-        double v = 1.0;
-        if (c.b_degrade) {
-            uint32_t w[4];
-            philox(c.k0, c.k1, c.env_id0 + (uint32_t)e, rmap, (uint32_t)cidx, STREAM_DEGRADE << 8, w);
-            const double d = u53(w[0], w[1]) * 0.4 + 0.6;
-            const double sel = u53(w[2], w[3]);
-            v = (sel < c.per_healthy) ? 1.0 : d;
-        }
-        p.degrade[base + cidx] = v;
+        p.degrade[base + cidx] = degrade_of(c, c.env_id0 + (uint32_t)e, rmap, cidx);
     }
 }
 
@@ -341,6 +354,8 @@ __device__ __forceinline__ void flush_usage(const DevCfg &c, const DevPtrs &p, i
             uint16_t u = hist[k];
             if (update && u > 50) {
                 p.health[base + k] = p.health[base + k] * p.degrade[base + k];
+                const uint8_t cnt = p.kmap[base + k];
+                if (cnt != 255) p.kmap[base + k] = (uint8_t)(cnt + 1);
                 u = 0;
             }
             p.usage[base + k] = u;
@@ -363,6 +378,8 @@ __device__ __forceinline__ void flush_usage(const DevCfg &c, const DevPtrs &p, i
         const uint32_t w = __hip_atomic_load(&u32[g >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not through this CU's L1
         if (((w >> (16 * (g & 1))) & 0xffffu) > 50) {
             p.health[g] = p.health[g] * p.degrade[g];
+            const uint8_t cnt = p.kmap[g];
+            if (cnt != 255) p.kmap[g] = (uint8_t)(cnt + 1);
             atomicAnd(&u32[g >> 1], (g & 1) ? 0x0000ffffu : 0xffff0000u);  // the neighbouring cell may belong to another lane
         }
     }
@@ -631,11 +648,16 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
             }
             double prob[N], draw[N];
             const bool use_draws = MAPS || a.uniforms != nullptr;
+            const bool compact = MAPS && c.compact;
+            uint8_t kcnt[N];
             if (use_draws) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
                     prob[i] = 1.0;
-                    if (MAPS) prob[i] = p.health[(size_t)e * cells + r.x[i] * c.L + r.y[i]];  // getMoveProb (dmfb.py:361-363)
+                    kcnt[i] = 0;
+                    // getMoveProb (dmfb.py:361-363): the float64 map, or one byte of the degrade-count map
+                    if (MAPS && !compact) prob[i] = p.health[(size_t)e * cells + r.x[i] * c.L + r.y[i]];
+                    if (compact) kcnt[i] = p.kmap[(size_t)e * cells + r.x[i] * c.L + r.y[i]];
                     if (a.uniforms) draw[i] = a.uniforms[a0 + i];
                 }
                 if (!a.uniforms) {
@@ -644,6 +666,15 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
                         uint32_t w[4];
                         philox(c.k0, c.k1, c.env_id0 + (uint32_t)e, r.rstep, (uint32_t)i, STREAM_MOVE << 8, w);
                         draw[i] = u53(w[0], w[1]);
+                    }
+                }
+                if (compact) {  // health = 1.0 * degrade * ... * degrade (count times), degrade from the map's Philox stream
+                    const uint32_t gen = c.b_degrade ? r.rmap - 1u : 0u;  // counter value the current maps were drawn with
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const int cell = r.x[i] * c.L + r.y[i];
+                        if (kcnt[i] == 255) prob[i] = p.health[(size_t)e * cells + cell];  // saturated count: the map itself
+                        else if (kcnt[i] != 0) prob[i] = health_from_count(degrade_of(c, c.env_id0 + (uint32_t)e, gen, cell), kcnt[i]);
                     }
                 }
             }
@@ -1022,7 +1053,7 @@ __global__ __launch_bounds__(kBlock) void k_reset(DevCfg c, DevPtrs p, const uin
             flush_usage(c, p, e, ulen, true, hist, lane);
         } else {  // new maps: whatever the log holds is discarded with the old usage map
             const size_t base = (size_t)e * cells;
-            for (int cidx = lane; cidx < cells; cidx += kWave) { p.health[base + cidx] = 1.0; p.usage[base + cidx] = 0; }
+            for (int cidx = lane; cidx < cells; cidx += kWave) { p.health[base + cidx] = 1.0; p.usage[base + cidx] = 0; p.kmap[base + cidx] = 0; }
             gen_degrade_env(c, p, cells, e, rmap, lane, kWave);
         }
     }

@@ -348,8 +348,10 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
         CREATE_TRY(hipMalloc(&h->dp.usage, cells * E * 2 + 4));  // + 4: the 32-bit atomics of the large-chip path stay in bounds
         d.ucap = d.max_step;
         CREATE_TRY(hipMalloc(&h->dp.ulog, (size_t)E * d.ucap * n * 2));
+        CREATE_TRY(hipMalloc(&h->dp.kmap, cells * E));
+        d.compact = 1;  // until health or degrade is replaced through dmfb_vec_set_map
         d.hist_bytes = (int)cells <= kHistMaxCells ? (int)((cells * 2 + 15) & ~(size_t)15) : 0;
-        h->bytes += cells * E * 18 + (size_t)E * d.ucap * n * 2;
+        h->bytes += cells * E * 19 + (size_t)E * d.ucap * n * 2;
     }
     // GenRandomBlocks guards (dmfb.py:230-234): no blocks on tiny chips or above 20 % coverage
     d.nb = cfg->n_blocks;
@@ -426,7 +428,7 @@ int dmfb_vec_destroy(dmfb_vec *h) {
     if (!h) return DMFB_OK;
     DeviceGuard g(h->cfg.device);
     (void)hipFree(h->dp.st); (void)hipFree(h->dp.starts); (void)hipFree(h->dp.health);
-    (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage); (void)hipFree(h->dp.ulog); (void)hipFree(h->zoom_dev); (void)hipFree(h->dp.blocks);
+    (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage); (void)hipFree(h->dp.ulog); (void)hipFree(h->dp.kmap); (void)hipFree(h->zoom_dev); (void)hipFree(h->dp.blocks);
     (void)hipFree(h->band_dev);
     for (int i = 0; i < 2 * dmfb_vec::kTimed; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -444,6 +446,7 @@ int dmfb_vec_reset(dmfb_vec *h, const uint8_t *d_mask, int new_flag, int8_t *d_o
     if (!h) return DMFB_ERR_BAD_ARG;
     DeviceGuard g(h->cfg.device);
     int rc = launch_reset(h, d_mask, new_flag ? 1 : 0, (hipStream_t)stream);
+    if (!rc && new_flag && !d_mask && h->dp.health) h->dc.compact = 1;  // every map is the generator's own again
     if (rc || !d_obs) return rc;
     return launch_observe(h, d_mask, d_obs, (hipStream_t)stream);
 }
@@ -549,6 +552,7 @@ int dmfb_vec_set_map(dmfb_vec *h, int which, const double *d_buf, void *stream) 
     DeviceGuard g(h->cfg.device);
     const size_t total = (size_t)h->cfg.n_envs * h->cfg.width * h->cfg.length;
     (void)hipGetLastError();  // drop stale errors left by other users of the runtime
+    if (which != DMFB_MAP_USAGE) h->dc.compact = 0;  // health / degrade no longer follow from the generator: gather the float64 map
     if (which == DMFB_MAP_USAGE) {  // pending log entries belong to the map that is being replaced: fold them in first
         hipLaunchKernelGGL(k_flush_usage, dim3((h->cfg.n_envs + (kBlock / kWave) - 1) / (kBlock / kWave)), dim3(kBlock), hist_lds(h),
                            (hipStream_t)stream, h->dc, h->dp);

@@ -25,7 +25,7 @@ def test_hip_replays_reference_golden(path):
     assert replay(path, _vec) > 0
 
 
-def _lockstep(cfg, E, steps, seed, autoreset, record=True, act_dtype=np.int32, greedy=0.6):
+def _lockstep(cfg, E, steps, seed, autoreset, record=True, act_dtype=np.int32, greedy=0.6, explicit_health=True):
     """Oracle and HIP env on the same Philox seed, same actions: every output must match."""
     O = DmfbOracle(n_envs=E, seed=seed, **cfg)
     V = _vec(n_envs=E, seed=seed, **cfg)
@@ -40,8 +40,9 @@ def _lockstep(cfg, E, steps, seed, autoreset, record=True, act_dtype=np.int32, g
         h = rng.random((E, cfg['width'], cfg['length'])) * 0.6 + 0.4
         u = rng.integers(40, 52, (E, cfg['width'], cfg['length'])).astype(np.float64)
         for B in (O, V):
-            B.set_map('health', h)
-            B.set_map('usage', u)
+            if explicit_health:   # replaces the generator's map: the kernel gathers the float64 health map
+                B.set_map('health', h)
+            B.set_map('usage', u)  # (with the generator's own maps the kernel rebuilds health from the degrade counts)
     O.reset(); V.reset()
     np.testing.assert_array_equal(O.observe(), V.observe())
     n = cfg['n_agents']
@@ -297,3 +298,34 @@ def test_usage_log_large_chip_global_atomic_path():
     # 80 x 70 = 5600 cells: above the LDS-histogram limit, the log is folded in with 32-bit global atomics on the u16 pairs
     _usage_log_walk(dict(width=80, length=70, n_agents=5, fov=5, b_degrade=True, per_degrade=0.5), E=9, steps=330, seed=7,
                     restart_every=0, check_every=100, reset_every=60)
+
+
+def test_lockstep_E_generator_maps_compact_health_path():
+    """Maps never replaced from outside: the transition rebuilds a cell's health from its degrade count (DevPtrs::kmap) and
+    the Philox degrade factor; transitions and all three maps must still match the oracle, which keeps plain float64 maps."""
+    assert _lockstep(Ecfg, E=160, steps=400, seed=33, autoreset=True, greedy=0.8, explicit_health=False) > 100
+    _lockstep(dict(width=12, length=9, n_agents=3, fov=7, b_degrade=True, per_degrade=0.6), E=90, steps=200, seed=34, autoreset=False,
+              greedy=0.7, explicit_health=False)
+
+
+def test_degrade_count_saturates_at_255():
+    """More than 255 degradations of a cell: the byte count saturates and the transition falls back to the float64 map."""
+    cfg = dict(width=10, length=10, n_agents=4, fov=9, b_degrade=True, per_degrade=1.0)
+    E, seed = 12, 35
+    O = DmfbOracle(n_envs=E, seed=seed, **cfg)
+    V = _vec(n_envs=E, seed=seed, **cfg)
+    over = np.full((E, 10, 10), 60.0)
+    for k in range(262):                 # every reset degrades every cell once (usage 60 > 50)
+        for B in (O, V):
+            B.set_map('usage', over)
+            B.reset()
+    np.testing.assert_array_equal(_bits(O.get_map('health')), _bits(V.get_map('health')))
+    rng = np.random.default_rng(seed)
+    assert O.get_map('health').max() < 1.0
+    for t in range(60):
+        a = rng.integers(0, 5, (E, 4)).astype(np.int32)
+        ro, do, co, so = O.step(a)
+        rv, dv, cv, sv = V.step(a)
+        np.testing.assert_array_equal(_bits(ro), _bits(rv), err_msg='rewards t=%d' % t)
+        np.testing.assert_array_equal(O.get_state()['pos'], V.get_state()['pos'], err_msg='pos t=%d' % t)
+    np.testing.assert_array_equal(O.observe(), V.observe())
