@@ -39,4 +39,27 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60 \
     --sizes 4096,262144 --msizes 4096,65536 --iters 24 --observe > $OUT/pmc_write.log 2>&1
 python3 $REPO/tools/reduce_profiles.py traffic $OUT/pmc_fetch $OUT/pmc_write $SUM/traffic.json $OUT/labels.json
+echo "== write-pattern and counter-calibration probes ==" ; date
+if [ -x $REPO/tools/probe/write_probe_bin ]; then
+  $REPO/tools/probe/write_probe_bin 642 1840 4 > $SUM/write_probe_642MB.txt 2>&1 || true
+  $REPO/tools/probe/write_probe_bin 257 1840 4 > $SUM/write_probe_257MB.txt 2>&1 || true
+fi
+if [ -x $REPO/tools/probe/fetch_calib_bin ]; then
+  rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv \
+      -d $OUT/calib_req -- $REPO/tools/probe/fetch_calib_bin > $OUT/calib_req.log 2>&1 || true
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib_fetch -- $REPO/tools/probe/fetch_calib_bin > $OUT/calib_fetch.log 2>&1 || true
+  python3 - <<PY > $SUM/fetch_calibration.txt
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for d in ('calib_req', 'calib_fetch'):
+    for f in glob.glob('$OUT/%s/**/*_counter_collection.csv' % d, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r['Kernel_Name'].startswith('k_'):
+                acc[(r['Kernel_Name'].split('(')[0], r['Counter_Name'])].append(float(r['Counter_Value']))
+print('k_stream reads 1 GiB per launch (16 B per lane, coalesced); k_gather8 makes 16 Mi isolated 8-byte gathers per launch')
+for k, v in sorted(acc.items()):
+    print('%-10s %-26s %.1f' % (k[0], k[1], sum(v) / len(v)))
+PY
+  cat $SUM/fetch_calibration.txt
+fi
 echo "== done ==" ; date
