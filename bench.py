@@ -59,7 +59,11 @@ def parse(argv=None):
     ap.add_argument('--width', type=int, default=10)
     ap.add_argument('--length', type=int, default=10)
     ap.add_argument('--drop_num', type=int, default=4)
-    ap.add_argument('--fov', type=int, default=9)
+    ap.add_argument('--fov', type=int, default=None, help='default 9 (dmfb) / 19 (meda)')
+    ap.add_argument('--env', choices=['dmfb', 'meda'], default='dmfb', help='meda: MEDAEnv_v0_2 observation (the one that trains)')
+    ap.add_argument('--degrade', action='store_true', help='b_degrade=True, per_degrade=1.0 (BASELINE config 5 / evaDegre.py chips)')
+    ap.add_argument('--eval_only', action='store_true',
+                    help='a step = one GREEDY evaluation episode per chip, no learn (Evaluator.evaluate / evaDegre.py path)')
     ap.add_argument('--batch_size', type=int, default=512, help='episodes per learn')
     ap.add_argument('--train_time', type=int, default=4, help='learns per round')
     ap.add_argument('--buffer_size', type=int, default=16384, help='episodes kept in the HBM replay buffer')
@@ -134,7 +138,7 @@ def env_only_tier(cfg, E, iters, device, fov_kernel=False):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
-    b = algo_bytes_per_env_step(cfg['n_agents'], cfg['fov'])
+    b = algo_bytes_per_env_step(cfg['n_agents'], cfg['fov'], degrade=bool(cfg.get('b_degrade')))
     out = {'n_envs': E, 'us_per_lockstep': round(us, 2), 'env_steps_per_s': round(E / us * 1e6),
            'algo_bytes_per_env_step': b, 'algo_GBps': round(E * b / us / 1e3, 1),
            'frac': round(E * b / us / 1e3 / HBM_PEAK_GBPS, 4)}
@@ -218,8 +222,8 @@ def in_loop_step_kernel(trainer, env, n, fov):
     torch.cuda.synchronize()
     ev = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in pairs)
     raw = sum(us) / max(1, len(us))
-    b = algo_bytes_per_env_step(n, fov)
-    return {'kernel': 'dmfbk::k_step<%d,false>' % n, 'n_envs': env.n_envs, 'launches_timed': len(us),
+    b = algo_bytes_per_env_step(n, fov, degrade=env.has_maps)
+    return {'kernel': 'dmfbk::k_step<%d,%s>' % (n, 'true' if env.has_maps else 'false'), 'n_envs': env.n_envs, 'launches_timed': len(us),
             'event_pair_raw_us': round(raw, 2), 'empty_event_pair_us': round(ev[len(ev) // 2], 2),
             'algo_bytes_per_env_step': b, 'algo_GBps_raw': round(env.n_envs * b / raw / 1e3, 1),
             'frac_raw': round(env.n_envs * b / raw / 1e3 / HBM_PEAK_GBPS, 4),
@@ -389,24 +393,39 @@ def main(argv=None):
     from marl_dmfb_amd.env.dmfb import VecDMFB
     from marl_dmfb_amd.train import Trainer
 
+    meda = a.env == 'meda'
+    if a.fov is None:
+        a.fov = 19 if meda else 9
     cfg = dict(width=a.width, length=a.length, n_agents=a.drop_num, fov=a.fov)
-    env = VecDMFB(n_envs=a.n_envs, seed=1234, env_id0=rank * a.n_envs, device=device, **cfg)
-    args = make_args(drop_num=a.drop_num, width=a.width, length=a.length, fov=a.fov, device=str(device), dist=dist,
+    if a.degrade:
+        cfg.update(b_degrade=True, per_degrade=1.0)
+    if meda:
+        from marl_dmfb_amd.env.meda import VecMEDA
+        env = VecMEDA(n_envs=a.n_envs, seed=1234, env_id0=rank * a.n_envs, device=device, version=2, **cfg)
+    else:
+        env = VecDMFB(n_envs=a.n_envs, seed=1234, env_id0=rank * a.n_envs, device=device, **cfg)
+    args = make_args(name=a.env, drop_num=a.drop_num, width=a.width, length=a.length, fov=a.fov, device=str(device), dist=dist,
                      n_envs=a.n_envs, batch_size=a.batch_size, train_time=a.train_time, buffer_size=a.buffer_size,
                      use_graph=a.graph, force_dist=force_dist,
                      **env.get_env_info())
     torch.manual_seed(1234 + rank)
     trainer = Trainer(env, args)
 
+    def one_step():
+        if not a.eval_only:
+            return trainer.collect_and_learn()
+        trainer.rolloutWorker._generate_episode()  # greedy episode on every chip; the chips keep ageing (evaDegre.py:19-22)
+        return int(trainer.rolloutWorker.last_played.item())
+
     for _ in range(a.warmup):
-        trainer.collect_and_learn()
+        one_step()
     torch.cuda.synchronize()
     if dist:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     played = 0
     for _ in range(a.steps):
-        played += trainer.collect_and_learn()
+        played += one_step()
     torch.cuda.synchronize()
     if dist:
         torch.distributed.barrier()
@@ -430,22 +449,51 @@ def main(argv=None):
         return 0
 
     n, fov = a.drop_num, a.fov
+    what = ('MEDA' if meda else 'DMFB') + (' degrade' if a.degrade else '')
     out = {
-        'metric': 'env-steps/sec (whole node), %dx%d DMFB %d-droplet fov%d' % (a.width, a.length, n, fov),
+        'metric': 'env-steps/sec (whole node), %dx%d %s %d-droplet fov%d' % (a.width, a.length, what, n, fov),
         'value': round(played_all / dt_max, 1), 'unit': 'env-steps/s', 'n_gpus': joined, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': round(dt_max / a.steps * 1e3, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8 env state/obs + f64 rewards; fp32 Q-net',
         'data': 'synthetic (Philox task generator, random-init CRNN)',
-        'config': {'workload': 'DMFB %dx%d, drop_num=%d, fov=%d, %d parallel envs per GPU%s' % (
-            a.width, a.length, n, fov, a.n_envs,
-            ' (BASELINE configs[1])' if (a.width, a.length, n, fov, a.n_envs) == (10, 10, 4, 9, 4096) else ''),
-            'round': 'one episode per chip (<=%d lock-steps) + %d learns x %d episodes' % (
-                env.max_step, a.train_time, a.batch_size),
+        'config': {'workload': '%s %dx%d, drop_num=%d, fov=%d, %d parallel envs per GPU%s' % (
+            what, a.width, a.length, n, fov, a.n_envs,
+            ' (BASELINE configs[1])' if (a.env, a.degrade, a.width, a.length, n, fov, a.n_envs) == ('dmfb', False, 10, 10, 4, 9, 4096) else ''),
+            'round': ('one GREEDY evaluation episode per chip (<=%d lock-steps), no learn' % env.max_step) if a.eval_only else
+                     'one episode per chip (<=%d lock-steps) + %d learns x %d episodes' % (env.max_step, a.train_time, a.batch_size),
             'parallelism': 'dp%d: chips sharded per rank, one flat RCCL all-reduce per learn' % world,
             'env_steps_per_round': round(played_all / a.steps, 1)},
     }
     tiers = {}
-    if world == 1 and not a.no_tiers:
+    if meda:  # roofline of the MEDA observation kernel: back-to-back launches between two HIP events
+        roof_E = min(a.roofline_envs, 65536)
+        trainer = None
+        env.close()
+        torch.cuda.empty_cache()
+        from marl_dmfb_amd.env.meda import VecMEDA
+        big = VecMEDA(n_envs=roof_E, seed=1, device=device, version=2, **cfg)
+        big.reset()
+        for _ in range(10):
+            big.observe()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            big.observe()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 100
+        fb = n * (3 * fov * fov + 2) + 5 * n + 8
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'k_meda_observe (obs_version 2)', 'achieved': round(roof_E * fb / us / 1e3, 1),
+                           'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(roof_E * fb / us / 1e3 / HBM_PEAK_GBPS, 4), 'traffic': None,
+                           'envs_per_launch': roof_E, 'algo_bytes_per_env': fb, 'avg_launch_us': round(us, 2), 'launches_timed': 100,
+                           'timing': 'HIP events on the launch stream around 100 back-to-back launches, nothing subtracted'}
+        big.close()
+        print(json.dumps(out), flush=True)
+        if dist:
+            torch.distributed.destroy_process_group()
+        return 0
+    if world == 1 and not a.no_tiers and not a.eval_only:
         tiers.update(loop_breakdown(trainer, max(2, min(a.steps, 6))))
         tiers['env_policy_learn'] = {'env_steps_per_s': out['value'], 'what': out['config']['round']}
         tiers['in_loop_step_kernel'] = in_loop_step_kernel(trainer, env, n, fov)
@@ -475,7 +523,7 @@ def main(argv=None):
             tiers['env_only_%d' % a.n_envs] = env_only_tier(cfg, a.n_envs, 300, device)
     if tiers:
         out['tiers'] = tiers
-    if not a.no_cpu_baseline and world == 1:
+    if not a.no_cpu_baseline and world == 1 and not a.eval_only:
         out['cpu_baseline'] = cpu_baseline(cfg, a)
     print(json.dumps(out), flush=True)
     if dist:

@@ -173,6 +173,7 @@ class Evaluator:
             ep['r'] *= valid
             ep['avail_u'][:] = v4
             ep['avail_u_next'][:] = v4
+        self.last_played = steps.sum()  # env steps actually played this round (before the failure inflation below)
         steps = torch.where(success > 0, steps, torch.full_like(steps, self.episode_limit))
         return reward, steps, constraints, success, ep, eps.reshape(())
 
