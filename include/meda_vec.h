@@ -100,8 +100,9 @@ int meda_vec_get_map(const meda_vec *h, int which, double *d_buf, void *stream);
 int meda_vec_set_map(meda_vec *h, int which, const double *d_buf, void *stream);
 
 /* How the handle maps chips to workgroups (profiling aid; no reference counterpart): out[0] = chips per workgroup of
- * the transition kernel, out[1] = chips per workgroup of the observation kernel. */
-int meda_vec_launch_shape(const meda_vec *h, int32_t out[2]);
+ * the transition kernel, out[1] = chips per tile of the observation kernel, out[2] = its threads per workgroup,
+ * out[3] = its (persistent) workgroup count. */
+int meda_vec_launch_shape(const meda_vec *h, int32_t out[4]);
 
 const char *meda_vec_strerror(int code);
 int meda_vec_last_hip_error(void);

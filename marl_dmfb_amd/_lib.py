@@ -131,7 +131,7 @@ def meda_vec():
     lib.meda_vec_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.meda_vec_get_map.argtypes = [vp, i32, vp, vp]
     lib.meda_vec_set_map.argtypes = [vp, i32, vp, vp]
-    lib.meda_vec_launch_shape.argtypes = [vp, C.POINTER(C.c_int32 * 2)]
+    lib.meda_vec_launch_shape.argtypes = [vp, C.POINTER(C.c_int32 * 4)]
     lib.meda_vec_strerror.argtypes = [i32]
     lib.meda_vec_strerror.restype = C.c_char_p
     lib.meda_vec_last_hip_error.argtypes = []

@@ -952,10 +952,13 @@ __global__ __launch_bounds__(kObsBlock) void k_observe(DevCfg c, DevPtrs p, cons
         const int tv = min(T, E - tile_base);
         // this barrier publishes the positions unpacked during the previous tile and separates its stream-out (LDS
         // reads) from the zero fill below; the loader's lanes flag and count the chips to refresh
+        // (flags double-buffered like the positions: the loader reaches the next tile while the other waves may still
+        // read this tile's flags in the partial stream-out; the second buffer is the carve's usage-log slot, unused here)
+        uint8_t *const flag = buf ? (uint8_t *)t0.ulen : t0.flag;
         bool refresh = false;
         if (loader && ltid < tv) {
             refresh = !mask || mask[tile_base + ltid] != 0;
-            t0.flag[ltid] = (uint8_t)refresh;
+            flag[ltid] = (uint8_t)refresh;
         }
         const int cnt = __syncthreads_count(refresh);
         DMFB_STAMP(0);
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(kObsBlock) void k_observe(DevCfg c, DevPtrs p, cons
             copy_tile_out(t, shift, gobs, (size_t)tile_base * row_bytes, tv * row_bytes, tid, kWork);
         } else if (cnt != 0) {
             for (int s = 0; s < tv; ++s)
-                if (t0.flag[s])
+                if (flag[s])
                     for (int b = tid; b < row_bytes; b += kWork)
                         gobs[(size_t)(tile_base + s) * row_bytes + b] = t.obs[(size_t)s * row_bytes + b];
         }

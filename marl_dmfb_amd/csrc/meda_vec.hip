@@ -16,70 +16,125 @@ using namespace medak;
 
 namespace {
 
-// ---- MEDAEnv.getOneObs (meda.py:613-674), LDS-staged --------------------------------------------------
-// A workgroup owns T consecutive chips = T*n rows of 4*fov*fov+2 bytes.  The tile sits in LDS at
-// the same 16-byte phase as its destination in HBM (shift = global offset & 15), so the body of the
-// tile streams out with aligned 16-byte loads/stores whatever T, n and fov are.  Rows are filled by
-// waves: two rows per wave pass (lanes 0-24 and 32-56 each own one cell of a 5x5 footprint); a row is
-// always written by ONE wave, and LDS operations of one wave complete in order, so for overlapping
+// diagnostic build only (-DMEDA_ABLATE, tools/ab_meda_obs.py): phases of the observation kernel switched off by a
+// device-side bit mask, to see what each costs.  Never defined for the product library.
+#ifdef MEDA_ABLATE
+__device__ int g_ablate;
+#define ABL(bit) (g_ablate & (bit))
+#else
+#define ABL(bit) 0
+#endif
+
+// ---- MEDAEnv.getOneObs (meda.py:613-674) and MEDAEnv_v0_2.getOneObs (meda.py:850-897), LDS-staged ----------
+// Persistent workgroups (the grid covers the CUs a few times over; a workgroup walks tiles blockIdx.x,
+// blockIdx.x + gridDim.x, ...).  A tile is T consecutive chips = T*n rows of obs_len bytes, built in LDS at the
+// same 16-byte phase as its destination in HBM (shift = global offset & 15), so its body streams out with
+// aligned 16-byte stores whatever T, n and fov are.
+// Roles, as in dmfbk::k_observe: the LAST wave is the loader -- it alone reads global memory (droplet words, one
+// chip per lane; the refresh mask) and never stores; the other waves stream finished tiles out and never load
+// (gfx950 counts a wave's loads and stores in one in-order counter).  The droplet words run two tiles ahead:
+// while tile k is filled, those of tile k+1 sit in the loader's registers; while tile k streams out they are
+// written to the second word buffer and tile k+2 is requested.
+// Rows are filled by waves, two rows per wave pass (lanes 0-24 and 32-56 each own one cell of a 5x5 footprint);
+// a row is always written by ONE wave, and LDS operations of one wave complete in order, so for overlapping
 // footprints the higher droplet index wins exactly as in the reference's sequential loops.
-__global__ __launch_bounds__(kBlock) void k_meda_observe(MCfg c, MPtrs p, const uint8_t *mask, int8_t *gobs) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int T = c.T, E = c.E, n = c.n, fov = c.fov, ff = c.ff;
-    const int tid = threadIdx.x;
-    const int tile_base = blockIdx.x * T;
-    const int tv = min(T, E - tile_base);
-    bool all = true, any = true;
-    if (mask) {
-        int cnt = 0;
-        for (int s = 0; s < tv; ++s) cnt += mask[tile_base + s] != 0;
-        all = cnt == tv; any = cnt > 0;
+constexpr int kObsBlock = 256;
+constexpr int kObsWork = kObsBlock - kWave;  // threads that stream tiles out
+
+__host__ __device__ inline size_t obs_tile_area(int T, int row_bytes) { return ((size_t)T * row_bytes + 16 + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t obs_lds_bytes(int T, int n, int row_bytes) {
+    return obs_tile_area(T, row_bytes) + 2 * (size_t)T * n * 4 + 2 * (((size_t)T + 15) & ~(size_t)15) + 512;
+}
+
+// One 5x5 footprint (value val, centre (x0, y0) in window coordinates) into a window layer [y][x]: every cell is
+// clamped into the window.  For a footprint that touches the window this writes exactly its in-window cells (a cell
+// outside lands on the window edge, which the footprint then covers); for a goal it is np.clip's smear (meda.py:665,
+// 872).  The caller predicates footprints that miss the window entirely.
+__device__ __forceinline__ void put5x5(int8_t *layer, int fov, int x0, int y0, int8_t val) {
+    int xs[2 * kR + 1], ys[2 * kR + 1];
+#pragma unroll
+    for (int k = 0; k <= 2 * kR; ++k) {
+        xs[k] = min(max(x0 + k - kR, 0), fov - 1);
+        ys[k] = min(max(y0 + k - kR, 0), fov - 1) * fov;
     }
-    if (!any) return;
-    const int row_bytes = n * c.obs_len;
-    const size_t g0 = (size_t)tile_base * row_bytes;
-    const int shift = (int)(((uintptr_t)gobs + g0) & 15);
-    const int bytes = tv * row_bytes;
-    int8_t *tile = (int8_t *)smem + shift;
-    uint32_t *words = (uint32_t *)(smem + (((size_t)T * row_bytes + 16 + 15) & ~(size_t)15));  // [T*n] droplet words
-    for (int it = tid; it < tv * n; it += kBlock) {
-        const int s = it / n, i = it - s * n;
-        words[it] = p.st[(size_t)i * E + tile_base + s];
-    }
-    {
-        uint4 *z = (uint4 *)smem;
-        const uint4 zero = make_uint4(0, 0, 0, 0);
-        for (int i = tid; i < (shift + bytes + 15) / 16; i += kBlock) z[i] = zero;
-    }
-    __syncthreads();
+#pragma unroll
+    for (int ky = 0; ky <= 2 * kR; ++ky)
+#pragma unroll
+        for (int kx = 0; kx <= 2 * kR; ++kx) layer[ys[ky] + xs[kx]] = val;
+}
+__device__ __forceinline__ bool touches(int x0, int y0, int fov) {  // some footprint cell inside the window
+    return x0 + kR >= 0 && x0 - kR <= fov - 1 && y0 + kR >= 0 && y0 - kR <= fov - 1;
+}
+
+// Fill of one zeroed LDS tile (all waves of the workgroup): words = [tv*n] droplet words.  An item is one LAYER of
+// one observation row and belongs to one lane, which writes that layer's droplets in the reference's order (later
+// writes win, as in its sequential loops); waves are layer-uniform.  The v0_2 boundary bands are a phase of their
+// own, one lane per window line, before a barrier.
+__device__ __forceinline__ void fill_rows(const MCfg &c, int8_t *tile, const uint32_t *words, const int8_t *zoom, int tv, int tid) {
+    const int n = c.n, fov = c.fov, ff = c.ff, hf = fov / 2;
     const int wave = tid / kWave, lane = tid % kWave;
-    const int half = lane >> 5, k = lane & 31;
     const int rows = tv * n;
-    for (int r0 = wave * 2; r0 < rows; r0 += 2 * (kBlock / kWave)) {
-        const int r = r0 + half;
-        const bool on = (r < rows) && (k < 25);
-        const int rr = r < rows ? r : rows - 1;
-        const int s = rr / n, a = rr - s * n;
-        const uint32_t wa = words[rr];
-        const int cx = wa & 0xff, cy = (wa >> 8) & 0xff, gxa = (wa >> 16) & 0xff, gya = wa >> 24;
-        const int ox = cx - fov / 2, oy = cy - fov / 2;
-        const int kx = k % 5 - kR, ky = k / 5 - kR;
-        int8_t *row = tile + (size_t)rr * c.obs_len;
-        if (c.version == 2) {
-            // ---- MEDAEnv_v0_2.getOneObs (meda.py:850-897)
-            const int hf = fov / 2;
+    constexpr int kWaves = kObsBlock / kWave;
+    if (c.version == 2) {
+        // ---- MEDAEnv_v0_2.getOneObs (meda.py:850-897)
+        // layer 2: boundary bands with the reference's axis mix-up (meda.py:880-890).  A bit per column, spread to one
+        // byte per bit four columns at a time and OR-ed into the zeroed tile (lines are fov bytes long, so neighbouring
+        // lanes share words: atomic OR)
+        if (!ABL(2))
+        for (int it = tid; it < rows * fov; it += kObsBlock) {
+            const int r = it / fov, wr = it - r * fov;
+            const uint32_t wa = words[r];
+            const int cx = wa & 0xff, cy = (wa >> 8) & 0xff;
+            const int left = hf - cx, right = hf - (c.W - 1 - cx);
+            const int up = hf - cy, down = hf - (c.L - 1 - cy);
+            int c0 = 0, c1 = 0;
+            if (up > 0) { c0 = 0; c1 = up < fov ? up : fov; }
+            else if (down > 0) { c0 = fov - down < 0 ? 0 : fov - down; c1 = fov; }
+            const bool full = left > 0 ? (wr < left) : (right > 0 ? (wr >= fov - right) : false);
+            int8_t *dst = tile + (size_t)r * c.obs_len + 2 * ff + wr * fov;
+            if (fov > 28) {  // wide windows: plain byte stores
+                const int b0 = full ? 0 : c0, b1 = full ? fov : c1;
+                for (int cc = b0; cc < b1; ++cc) dst[cc] = 1;
+                continue;
+            }
+            const uint32_t colbits = full ? ((1u << fov) - 1u) : ((1u << c1) - (1u << c0));
+            if (colbits) {
+                const int ph = (int)((uintptr_t)dst & 3);
+                uint32_t *w = (uint32_t *)(dst - ph);
+                const unsigned long long bits = (unsigned long long)colbits << ph;
+                for (int q = 0; q * 4 < fov + 3; ++q) {
+                    const uint32_t v = ((uint32_t)((bits >> (4 * q)) & 15u) * 0x00204081u) & 0x01010101u;
+                    if (v) atomicOr(w + q, v);
+                }
+            }
+        }
+        __syncthreads();  // the byte stores below may share a word with a band's atomic
+        // waves 0,2: layer 0 + direction bytes; waves 1,3: layer 1
+        const int layer = wave & 1;
+        for (int r = (wave >> 1) * kWave + lane; r < rows; r += (kWaves / 2) * kWave) {
+            const int s = r / n, a = r - s * n;
+            const uint32_t wa = words[r];
+            const int cx = wa & 0xff, cy = (wa >> 8) & 0xff, gxa = (wa >> 16) & 0xff, gya = wa >> 24;
+            const int ox = cx - hf, oy = cy - hf;
+            int8_t *row = tile + (size_t)r * c.obs_len;
+            if (layer == 0) {
+                if (!ABL(4))
+                for (int j = 0; j < n; ++j) {  // every droplet, ascending index
+                    const uint32_t wj = words[s * n + j];
+                    const int x0 = (int)(wj & 0xff) - ox, y0 = (int)((wj >> 8) & 0xff) - oy;
+                    if (touches(x0, y0, fov)) put5x5(row, fov, x0, y0, (int8_t)(j + 1));
+                }
+                row[3 * ff] = zoom[gya - cy + 128];
+                row[3 * ff + 1] = zoom[256 + gxa - cx + 128];
+                continue;
+            }
             // members of the `observed` set: droplets with at least one footprint cell inside the window
             uint32_t obs_mask = 0;
             for (int j = 0; j < n; ++j) {
                 const uint32_t wj = words[s * n + j];
-                const int xj = wj & 0xff, yj = (wj >> 8) & 0xff;
-                const bool vis = (xj + kR >= ox) && (xj - kR <= ox + fov - 1) && (yj + kR >= oy) && (yj - kR <= oy + fov - 1);
-                obs_mask |= (uint32_t)vis << j;
-                if (on) {  // layer 0: every droplet, ascending index
-                    const int nx = xj + kx - ox, ny = yj + ky - oy;
-                    if (nx >= 0 && nx < fov && ny >= 0 && ny < fov) row[ny * fov + nx] = (int8_t)(j + 1);
-                }
+                obs_mask |= (uint32_t)touches((int)(wj & 0xff) - ox, (int)((wj >> 8) & 0xff) - oy, fov) << j;
             }
+            if (ABL(1)) obs_mask = 0;
             // iteration order of the CPython set (see oracle/meda_oracle.c): ascending once it has had 5
             // members (table resized to 32 slots), else slot order of the 8-slot table
             unsigned long long order = 0;  // 4-bit entries
@@ -98,72 +153,129 @@ __global__ __launch_bounds__(kBlock) void k_meda_observe(MCfg c, MPtrs p, const 
                 for (int i = 0; i < 8; ++i)
                     if ((slots >> (5 * i)) & 16) { order |= ((slots >> (5 * i)) & 15) << (4 * cnt); ++cnt; }
             }
-            for (int tt = 0; tt < cnt; ++tt) {  // layer 1: clipped goals of the observed OTHER droplets
+            for (int tt = 0; tt < cnt; ++tt) {  // clipped goals of the observed OTHER droplets, in set order
                 const int j = (int)((order >> (4 * tt)) & 15);
-                if (on && j != a) {
-                    const uint32_t wj = words[s * n + j];
-                    int mx = (int)((wj >> 16) & 0xff) + kx - ox, my = (int)(wj >> 24) + ky - oy;
-                    mx = mx < 0 ? 0 : (mx > fov - 1 ? fov - 1 : mx);
-                    my = my < 0 ? 0 : (my > fov - 1 ? fov - 1 : my);
-                    row[ff + my * fov + mx] = (int8_t)(j + 1);
-                }
+                if (j == a) continue;
+                const uint32_t wj = words[s * n + j];
+                put5x5(row + ff, fov, (int)((wj >> 16) & 0xff) - ox, (int)(wj >> 24) - oy, (int8_t)(j + 1));
             }
-            if (r < rows) {  // layer 2: boundary bands with the reference's axis mix-up (meda.py:880-890)
-                const int left = hf - cx, right = hf - (c.W - 1 - cx);
-                const int up = hf - cy, down = hf - (c.L - 1 - cy);
-                int c0 = 0, c1 = 0;
-                if (up > 0) { c0 = 0; c1 = up < fov ? up : fov; }
-                else if (down > 0) { c0 = fov - down < 0 ? 0 : fov - down; c1 = fov; }
-                for (int rr = k; rr < fov; rr += 32) {
-                    const bool full = left > 0 ? (rr < left) : (right > 0 ? (rr >= fov - right) : false);
-                    const int b0 = full ? 0 : c0, b1 = full ? fov : c1;
-                    for (int cc = b0; cc < b1; ++cc) row[2 * ff + rr * fov + cc] = 1;
-                }
-                if (k == 0) {
-                    row[3 * ff] = p.zoom[gya - cy + 128];
-                    row[3 * ff + 1] = p.zoom[256 + gxa - cx + 128];
-                }
-            }
-            continue;
         }
-        if (on) {
-            {   // layer 0: own footprint
-                const int nx = cx + kx - ox, ny = cy + ky - oy;
-                if (nx >= 0 && nx < fov && ny >= 0 && ny < fov) row[ny * fov + nx] = (int8_t)(a + 1);
-            }
-            {   // layer 1: own goal
-                const int nx = gxa + kx - ox, ny = gya + ky - oy;
-                if (nx >= 0 && nx < fov && ny >= 0 && ny < fov) row[ff + ny * fov + nx] = (int8_t)(a + 1);
-            }
-            if (k == 0) { row[4 * ff] = (int8_t)(gxa - cx); row[4 * ff + 1] = (int8_t)(gya - cy); }
-        }
-        for (int j = 0; j < n; ++j) {  // layers 2/3: the OTHER droplets and goals, ascending index
-            const uint32_t wj = words[s * n + j];
-            if (on && j != a) {
-                const int nx = (int)(wj & 0xff) + kx - ox, ny = (int)((wj >> 8) & 0xff) + ky - oy;
-                if (nx >= 0 && nx < fov && ny >= 0 && ny < fov) row[2 * ff + ny * fov + nx] = (int8_t)(j + 1);
-                int mx = (int)((wj >> 16) & 0xff) + kx - ox, my = (int)(wj >> 24) + ky - oy;
-                mx = mx < 0 ? 0 : (mx > fov - 1 ? fov - 1 : mx);   // np.clip: goals outside the window smear onto its edge
-                my = my < 0 ? 0 : (my > fov - 1 ? fov - 1 : my);
-                row[3 * ff + my * fov + mx] = (int8_t)(j + 1);
+        return;
+    }
+    // ---- MEDAEnv.getOneObs (meda.py:613-674): wave = layer
+    const int layer = wave;
+    for (int r = lane; r < rows; r += kWave) {
+        const int s = r / n, a = r - s * n;
+        const uint32_t wa = words[r];
+        const int cx = wa & 0xff, cy = (wa >> 8) & 0xff, gxa = (wa >> 16) & 0xff, gya = wa >> 24;
+        const int ox = cx - hf, oy = cy - hf;
+        int8_t *row = tile + (size_t)r * c.obs_len;
+        if (layer == 0) {  // own footprint, direction
+            put5x5(row, fov, hf, hf, (int8_t)(a + 1));
+            row[4 * ff] = (int8_t)(gxa - cx);
+            row[4 * ff + 1] = (int8_t)(gya - cy);
+        } else if (layer == 1) {  // own goal, in-window cells only
+            if (touches(gxa - ox, gya - oy, fov)) put5x5(row + ff, fov, gxa - ox, gya - oy, (int8_t)(a + 1));
+        } else {  // 2: the OTHER droplets (in-window cells); 3: their goals, smeared onto the window edge; ascending index
+            for (int j = 0; j < n; ++j) {
+                if (j == a) continue;
+                const uint32_t wj = words[s * n + j];
+                if (layer == 2) {
+                    const int x0 = (int)(wj & 0xff) - ox, y0 = (int)((wj >> 8) & 0xff) - oy;
+                    if (touches(x0, y0, fov)) put5x5(row + 2 * ff, fov, x0, y0, (int8_t)(j + 1));
+                } else {
+                    put5x5(row + 3 * ff, fov, (int)((wj >> 16) & 0xff) - ox, (int)(wj >> 24) - oy, (int8_t)(j + 1));
+                }
             }
         }
     }
-    __syncthreads();
-    if (all) {
-        // head (< 16 bytes) and tail by bytes, body by aligned 16-byte vectors
-        const int head = (16 - shift) & 15;
-        const int hb = head < bytes ? head : bytes;
-        for (int b = tid; b < hb; b += kBlock) gobs[g0 + b] = tile[b];
-        const int n16 = (bytes - hb) >> 4;
-        const uint4 *src = (const uint4 *)(tile + hb);
-        uint4 *dst = (uint4 *)(gobs + g0 + hb);
-        for (int i = tid; i < n16; i += kBlock) dst[i] = src[i];
-        for (int b = hb + (n16 << 4) + tid; b < bytes; b += kBlock) gobs[g0 + b] = tile[b];
-    } else {
-        for (int s = 0; s < tv; ++s)
-            if (mask[tile_base + s])
-                for (int b = tid; b < row_bytes; b += kBlock) gobs[g0 + (size_t)s * row_bytes + b] = tile[(size_t)s * row_bytes + b];
+}
+
+template <int NW>  // droplet words the loader keeps per chip: n <= NW
+__global__ __launch_bounds__(kObsBlock) void k_meda_observe(MCfg c, MPtrs p, const uint8_t *mask, int8_t *gobs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int T = c.T, E = c.E, n = c.n;
+    const int tid = threadIdx.x;
+    const bool loader = tid >= kObsWork;
+    const int ltid = tid - kObsWork;
+    const int ntiles = (E + T - 1) / T;
+    const int row_bytes = n * c.obs_len;
+    uint32_t *const wbuf = (uint32_t *)(smem + obs_tile_area(T, row_bytes));  // [2][T*n] droplet words
+    uint8_t *const fbuf = (uint8_t *)(wbuf + 2 * (size_t)T * n);               // [2][align16(T)] refresh flags
+    const int fstride = (T + 15) & ~15;
+    const int8_t *const zoom = (const int8_t *)(fbuf + 2 * fstride);           // LDS copy of MPtrs::zoom (v0_2 only)
+    uint32_t rec[NW];
+    auto prefetch = [&](int tile) {  // unconditional loads from clamped (always valid) addresses: nothing to wait for here
+        const int base = tile < ntiles ? tile * T : 0;
+        const int chip = min(base + ltid, E - 1);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) rec[w] = p.st[(size_t)min(w, n - 1) * E + chip];
+    };
+    auto unpack = [&](int tile, uint32_t *dst) {
+        if (tile >= ntiles || ltid >= min(T, E - tile * T)) return;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            if (w < n) dst[ltid * n + w] = rec[w];
+    };
+    int tile = blockIdx.x, buf = 0;
+    if (loader) {
+        prefetch(tile);
+        if (c.version == 2)
+            for (int i = ltid; i < 128; i += kWave) ((uint32_t *)zoom)[i] = ((const uint32_t *)p.zoom)[i];
+        unpack(tile, wbuf);
+        prefetch(tile + gridDim.x);
+    }
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int tile_base = tile * T;
+        const int tv = min(T, E - tile_base);
+        const size_t g0 = (size_t)tile_base * row_bytes;
+        const int shift = (int)(((uintptr_t)gobs + g0) & 15);
+        const int bytes = tv * row_bytes;
+        int8_t *const tile_lds = (int8_t *)smem + shift;
+        const uint32_t *const words = wbuf + (size_t)buf * T * n;
+        uint8_t *const flag = fbuf + buf * fstride;
+        // this barrier publishes the words written during the previous tile's stream-out and separates that
+        // stream-out (LDS reads) from the zero fill below; the loader's lanes flag and count the chips to refresh
+        bool refresh = false;
+        if (loader && ltid < tv) {
+            refresh = !mask || mask[tile_base + ltid] != 0;
+            flag[ltid] = (uint8_t)refresh;
+        }
+        const int cnt = __syncthreads_count(refresh);
+        if (cnt != 0) {  // (uniform) something to refresh in this tile
+            if (!ABL(16)) {
+                uint4 *z = (uint4 *)smem;
+                const uint4 zero = make_uint4(0, 0, 0, 0);
+                for (int i = tid; i < (shift + bytes + 15) / 16; i += kObsBlock) z[i] = zero;
+            }
+            __syncthreads();
+            fill_rows(c, tile_lds, words, zoom, tv, tid);
+            __syncthreads();
+        }
+        if (loader) {
+            unpack(tile + gridDim.x, wbuf + (size_t)(buf ^ 1) * T * n);
+            prefetch(tile + 2 * gridDim.x);
+        } else if (ABL(8)) {
+        } else if (cnt == tv) {
+            // head (< 16 bytes) and tail by bytes, body 16 bytes per lane: four LDS reads in flight, then four stores
+            const int head = (16 - shift) & 15;
+            const int hb = head < bytes ? head : bytes;
+            for (int b = tid; b < hb; b += kObsWork) gobs[g0 + b] = tile_lds[b];
+            const int n16 = (bytes - hb) >> 4;
+            const uint4 *src = (const uint4 *)(tile_lds + hb);
+            uint4 *dst = (uint4 *)(gobs + g0 + hb);
+            int i = tid;
+            for (; i + 3 * kObsWork < n16; i += 4 * kObsWork) {
+                const uint4 v0 = src[i], v1 = src[i + kObsWork], v2 = src[i + 2 * kObsWork], v3 = src[i + 3 * kObsWork];
+                dst[i] = v0; dst[i + kObsWork] = v1; dst[i + 2 * kObsWork] = v2; dst[i + 3 * kObsWork] = v3;
+            }
+            for (; i < n16; i += kObsWork) dst[i] = src[i];
+            for (int b = hb + (n16 << 4) + tid; b < bytes; b += kObsWork) gobs[g0 + b] = tile_lds[b];
+        } else if (cnt != 0) {
+            for (int s = 0; s < tv; ++s)
+                if (flag[s])
+                    for (int b = tid; b < row_bytes; b += kObsWork) gobs[g0 + (size_t)s * row_bytes + b] = tile_lds[(size_t)s * row_bytes + b];
+        }
     }
 }
 
@@ -293,6 +405,8 @@ struct meda_vec {
     MPtrs dp;
     size_t bytes = 0;
     size_t obs_lds = 0;
+    int obs_grid = 1;    // persistent grid of the observation kernel
+    int n_cu = 256;
     int8_t zoom_host[512];
     int8_t *zoom_dev = nullptr;
 };
@@ -319,7 +433,11 @@ int launch_reset(meda_vec *h, const uint8_t *m, int mode, hipStream_t s) { DISPA
 
 int launch_observe(const meda_vec *h, const uint8_t *mask, int8_t *obs, hipStream_t s) {
     const int T = h->dc.T;
-    LAUNCH(k_meda_observe, dim3((h->cfg.n_envs + T - 1) / T), dim3(kBlock), h->obs_lds, s, h->dc, h->dp, mask, obs);
+    (void)T;
+    const dim3 grid(h->obs_grid), block(kObsBlock);
+    if (h->dc.n <= 4) LAUNCH(k_meda_observe<4>, grid, block, h->obs_lds, s, h->dc, h->dp, mask, obs);
+    else if (h->dc.n <= 8) LAUNCH(k_meda_observe<8>, grid, block, h->obs_lds, s, h->dc, h->dp, mask, obs);
+    else LAUNCH(k_meda_observe<MEDA_MAX_AGENTS>, grid, block, h->obs_lds, s, h->dc, h->dp, mask, obs);
     return MEDA_OK;
 }
 int launch_update_health(const meda_vec *h, hipStream_t s) {
@@ -343,7 +461,7 @@ int meda_vec_check_config(const meda_vec_config *c) {
     if (c->n_agents <= 0) return MEDA_ERR_NO_AGENTS;
     if (c->n_agents > (c->width / 15) * (c->length / 15)) return MEDA_ERR_TOO_MANY_DROPLETS;
     if (c->n_agents > MEDA_MAX_AGENTS || c->width > MEDA_MAX_DIM || c->length > MEDA_MAX_DIM || c->fov < 1) return MEDA_ERR_UNSUPPORTED;
-    if ((size_t)c->n_agents * (4 * c->fov * c->fov + 2) + 64 + (size_t)c->n_agents * 4 > 60 * 1024) return MEDA_ERR_UNSUPPORTED;
+    if (obs_lds_bytes(1, c->n_agents, c->n_agents * (4 * c->fov * c->fov + 2)) > 60 * 1024) return MEDA_ERR_UNSUPPORTED;  // one chip's rows must fit the LDS tile
     if (c->obs_version != 0 && c->obs_version != 2) return MEDA_ERR_UNSUPPORTED;
     if (c->n_envs <= 0) return MEDA_ERR_BAD_ARG;
     return MEDA_OK;
@@ -366,14 +484,31 @@ int meda_vec_create(const meda_vec_config *cfg, void *stream, meda_vec **out) {
     d.per_healthy = 1.0 - cfg->per_degrade;
     const int E = cfg->n_envs, n = cfg->n_agents;
     const size_t row = (size_t)n * d.obs_len;
-    size_t cap = 40 * 1024;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && v > 0) h->n_cu = v;
+    }
+    // observation tile, at most 64 chips (the loader wave keeps one chip per lane).  Measured on MI355X at 30x30, 4
+    // droplets, fov 19 (tools/probe/meda_tile_sweep.sh, profiles/r02/meda_tile_sweep.txt): the base observation is
+    // fastest with the largest tile (64 KB of LDS, two workgroups per CU: its fill is light, fewer barriers per
+    // byte), the v0_2 one with ~40 KB (four per CU: bands and the set order make its fill heavier, more overlap)
+    size_t cap = (cfg->obs_version == 2 ? 40 : 64) * 1024;
     if (const char *v = getenv("MEDA_VEC_TILE_KB")) cap = (size_t)atoi(v) * 1024;  // tuning knob
-    int T = (int)(cap / row);
-    if (T < 1) T = 1;
-    if (T > 32) T = 32;
-    while (T > 1 && (E + T - 1) / T < 512) --T;  // keep the grid wide for small batches
+    int T = 1;
+    while (T < 64 && obs_lds_bytes(T + 1, n, (int)row) <= cap) ++T;
+    while (T > 1 && (E + T - 1) / T < 2 * h->n_cu) --T;  // keep the grid wide for small batches
+    if (const char *v = getenv("MEDA_VEC_OBS_TILE")) {  // tuning knob: chips per tile
+        const int t = atoi(v);
+        if (t >= 1 && t <= 64 && obs_lds_bytes(t, n, (int)row) <= 64 * 1024) T = t;
+    }
     d.T = T;
-    h->obs_lds = (((size_t)T * row + 16 + 15) & ~(size_t)15) + (size_t)T * n * 4;
+    h->obs_lds = obs_lds_bytes(T, n, (int)row);
+    {
+        int per_cu = (int)((size_t)160 * 1024 / h->obs_lds);
+        per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+        const int ntiles = (E + T - 1) / T;
+        h->obs_grid = ntiles < h->n_cu * per_cu ? ntiles : h->n_cu * per_cu;
+    }
     hipStream_t s = (hipStream_t)stream;
     memset(&h->dp, 0, sizeof(h->dp));
     auto fail = [&](hipError_t e, const char *what, int line) { hip_fail(e, what, line); meda_vec_destroy(h); return MEDA_ERR_HIP; };
@@ -477,6 +612,18 @@ int meda_vec_step(meda_vec *h, const void *d_actions, const double *d_uniforms, 
 int meda_vec_observe(const meda_vec *h, const uint8_t *d_mask, int8_t *d_obs, void *stream) {
     if (!h || !d_obs) return MEDA_ERR_BAD_ARG;
     DeviceGuard g(h->cfg.device);
+#ifdef MEDA_ABLATE
+    {
+        const char *v = getenv("MEDA_ABLATE");
+        const int bits = v ? atoi(v) : 0;
+        static int last = 0;
+        if (bits != last) {
+            (void)hipStreamSynchronize((hipStream_t)stream);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &bits, sizeof(bits));
+            last = bits;
+        }
+    }
+#endif
     return launch_observe(h, d_mask, d_obs, (hipStream_t)stream);
 }
 
@@ -508,9 +655,9 @@ int meda_vec_set_map(meda_vec *h, int which, const double *d_buf, void *stream) 
     return MEDA_OK;
 }
 
-int meda_vec_launch_shape(const meda_vec *h, int32_t out[2]) {
+int meda_vec_launch_shape(const meda_vec *h, int32_t out[4]) {
     if (!h || !out) return MEDA_ERR_BAD_ARG;
-    out[0] = kBlock; out[1] = h->dc.T;
+    out[0] = kBlock; out[1] = h->dc.T; out[2] = kObsBlock; out[3] = h->obs_grid;
     return MEDA_OK;
 }
 

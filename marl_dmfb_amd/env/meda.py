@@ -156,9 +156,9 @@ class VecMEDA:
 
     def launch_shape(self):
         """Chips per workgroup of the launches the handle makes (include/meda_vec.h: meda_vec_launch_shape)."""
-        out = (C.c_int32 * 2)()
+        out = (C.c_int32 * 4)()
         _check(self.lib.meda_vec_launch_shape(self.h, C.byref(out)))
-        return {'step_tile': out[0], 'observe_tile': out[1]}
+        return {'step_tile': out[0], 'observe_tile': out[1], 'observe_block': out[2], 'observe_workgroups': out[3]}
 
     def get_state(self):
         E, n, dev = self.n_envs, self.n_agents, self.device

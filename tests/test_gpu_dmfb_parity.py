@@ -329,3 +329,33 @@ def test_degrade_count_saturates_at_255():
         np.testing.assert_array_equal(_bits(ro), _bits(rv), err_msg='rewards t=%d' % t)
         np.testing.assert_array_equal(O.get_state()['pos'], V.get_state()['pos'], err_msg='pos t=%d' % t)
     np.testing.assert_array_equal(O.observe(), V.observe())
+
+
+@pytest.mark.parametrize('cfg,E', [(A, 150001), (D, 40003)], ids=['A', 'D'])
+def test_observe_persistent_multi_tile_and_masks(cfg, E):
+    """Batches where every workgroup of the persistent observation kernel walks many tiles (records prefetched two
+    tiles ahead; positions and refresh flags double-buffered), whole and under partial masks: rows of masked-off
+    chips keep what the buffer held."""
+    from marl_dmfb_amd.env.dmfb import VecDMFB
+    from oracle.dmfb_oracle import DmfbOracle
+    V = VecDMFB(n_envs=E, seed=17, **cfg)
+    O = DmfbOracle(n_envs=E, seed=17, **cfg)
+    V.reset(); O.reset()
+    sh = V.launch_shape()
+    assert (E + sh['observe_tile'] - 1) // sh['observe_tile'] > 2 * sh['observe_workgroups']
+    rng = np.random.default_rng(3)
+    n = cfg['n_agents']
+    for t in range(3):
+        a = rng.integers(0, 5, (E, n)).astype(np.int32)
+        obs, r, d, info = V.step(torch.as_tensor(a, device='cuda'), autoreset=False)
+        O.step(a)
+        assert np.array_equal(obs.cpu().numpy(), O.observe()), 'obs differ at step %d' % t
+    want_full = O.observe()
+    for frac in (0.5, 0.03, 0.97):
+        mask = (rng.random(E) < frac).astype(np.uint8)
+        mask[:200] = 0; mask[-300:-100] = 1
+        buf = torch.full_like(V.obs, 77)
+        V.observe(mask=torch.as_tensor(mask, device='cuda'), obs=buf)
+        want = want_full.copy()
+        want[mask == 0] = 77
+        assert np.array_equal(buf.cpu().numpy(), want), 'masked observe differs at frac %.2f' % frac

@@ -132,6 +132,10 @@ def test_lockstep_v0_2_observation():
     _lockstep(dict(C30, version=2), E=300, steps=120, seed=20, autoreset=True)
     _lockstep(dict(width=60, length=75, n_agents=12, fov=19, version=2), E=64, steps=140, seed=21, autoreset=True, greedy=0.9)
     _lockstep(dict(width=30, length=60, n_agents=8, fov=9, version=2), E=50, steps=90, seed=22, autoreset=False)
+    # layer-2 bands: packed-word path with rows that are not word multiples (fov 5, 27) and the byte path (fov 31)
+    _lockstep(dict(width=30, length=45, n_agents=6, fov=5, version=2), E=33, steps=60, seed=23, autoreset=True)
+    _lockstep(dict(width=45, length=30, n_agents=5, fov=27, version=2), E=21, steps=60, seed=24, autoreset=True)
+    _lockstep(dict(width=30, length=30, n_agents=3, fov=31, version=2), E=17, steps=50, seed=25, autoreset=True)
 
 
 def test_meda_v0_2_trains_with_crnn():
@@ -154,3 +158,34 @@ def test_meda_v0_2_trains_with_crnn():
     assert played > 64 and tr.trained_times == args.train_time
     assert torch.isfinite(tr.agents.policy.last_loss)
     assert not torch.equal(w0, tr.agents.policy.eval_rnn.fc1.weight)
+
+
+@pytest.mark.parametrize('version', [0, 2])
+def test_observe_persistent_multi_tile_and_masks(version):
+    """Batches large enough that every workgroup of the persistent observation kernel walks several tiles (records
+    prefetched two tiles ahead, double-buffered words and refresh flags), whole and under partial masks: masked-off
+    chips keep their previous rows."""
+    from marl_dmfb_amd.env.meda import VecMEDA
+    cfg = dict(width=30, length=30, n_agents=4, fov=19, version=version)
+    E = 40000 + 7
+    V = VecMEDA(n_envs=E, seed=31, **cfg)
+    O = MedaOracle(n_envs=E, seed=31, **cfg)
+    V.reset(); O.reset()
+    sh = V.launch_shape()
+    assert (E + sh['observe_tile'] - 1) // sh['observe_tile'] > 2 * sh['observe_workgroups']
+    rng = np.random.default_rng(5)
+    for t in range(4):
+        a = rng.integers(0, 9, (E, 4)).astype(np.int32)
+        obs, r, d, info = V.step(torch.as_tensor(a, device='cuda'), autoreset=False)
+        O.step(a)
+        assert np.array_equal(obs.cpu().numpy(), O.observe()), 'obs differ at step %d' % t
+    # partial refresh: rows of masked-off chips must stay as they were (here: a sentinel)
+    for frac in (0.5, 0.02, 0.98):
+        mask = (rng.random(E) < frac).astype(np.uint8)
+        mask[:64] = 0; mask[-70:-6] = 1
+        buf = torch.full_like(V.obs, 77)
+        V.observe(mask=torch.as_tensor(mask, device='cuda'), obs=buf)
+        got = buf.cpu().numpy()
+        want = O.observe()
+        want[mask == 0] = 77
+        assert np.array_equal(got, want), 'masked observe differs at frac %.2f' % frac

@@ -44,7 +44,7 @@ def launch_labels(name, cfg, env, E):
     if cfg['meda']:
         ob = n * (4 * fov * fov + 2)
         out['medak::k_meda_step<%d>|%d' % (n, wgs(sh['step_tile']))] = {'key': 'k_meda_step_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (algo_bytes(cfg) - ob) * E}
-        out['(anonymous namespace)::k_meda_observe|%d' % wgs(sh['observe_tile'])] = {'key': 'k_meda_observe_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (ob + 5 * n + 8) * E}
+        out['(anonymous namespace)::k_meda_observe<%d>|%d' % (4 if n <= 4 else 8 if n <= 8 else 16, sh['observe_workgroups'] * sh['observe_block'])] = {'key': 'k_meda_observe_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (ob + 5 * n + 8) * E}
         return out
     ob = n * (3 * fov * fov + 2)
     maps = 'true' if cfg.get('b_degrade') else 'false'
