@@ -465,7 +465,7 @@ def main(argv=None):
             'env_steps_per_round': round(played_all / a.steps, 1)},
     }
     tiers = {}
-    if meda:  # roofline of the MEDA observation kernel: back-to-back launches between two HIP events
+    if meda:  # roofline of the MEDA observation kernel, timed like k_observe<n>: dispatch time stamps inside a lock-step loop
         roof_E = min(a.roofline_envs, 65536)
         trainer = None
         env.close()
@@ -473,21 +473,30 @@ def main(argv=None):
         from marl_dmfb_amd.env.meda import VecMEDA
         big = VecMEDA(n_envs=roof_E, seed=1, device=device, version=2, **cfg)
         big.reset()
-        for _ in range(10):
-            big.observe()
+        g = torch.Generator(device=device).manual_seed(0)
+        acts = [torch.randint(0, 9, (roof_E, n), device=device, generator=g, dtype=torch.int8) for _ in range(8)]
+        for i in range(10):
+            big.step(acts[i % 8], autoreset=True)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(100):
-            big.observe()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / 100
+        big.observe_timing(True)
+        for i in range(100):
+            big.step(acts[i % 8], autoreset=True)
+        us_sum, launches = big.observe_timing_read()
+        big.observe_timing(False)
+        us = us_sum / launches
         fb = n * (3 * fov * fov + 2) + 5 * n + 8
-        out['roofline'] = {'bound': 'hbm', 'kernel': 'k_meda_observe (obs_version 2)', 'achieved': round(roof_E * fb / us / 1e3, 1),
-                           'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(roof_E * fb / us / 1e3 / HBM_PEAK_GBPS, 4), 'traffic': None,
-                           'envs_per_launch': roof_E, 'algo_bytes_per_env': fb, 'avg_launch_us': round(us, 2), 'launches_timed': 100,
-                           'timing': 'HIP events on the launch stream around 100 back-to-back launches, nothing subtracted'}
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'traffic.json')))
+            traffic = tj.get('k_meda_observe_v0_2_%dx%d_%dd_E%d' % (cfg['width'], cfg['length'], n, roof_E))
+        except (OSError, ValueError):
+            pass
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'k_meda_observe<%d> (obs_version 2)' % (4 if n <= 4 else 8 if n <= 8 else 16),
+                           'achieved': round(roof_E * fb / us / 1e3, 1),
+                           'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(roof_E * fb / us / 1e3 / HBM_PEAK_GBPS, 4), 'traffic': traffic,
+                           'envs_per_launch': roof_E, 'algo_bytes_per_env': fb, 'avg_launch_us': round(us, 2), 'launches_timed': launches,
+                           'timing': 'HIP event pair per launch carrying the dispatch start/end time stamps, %d launches, inside an '
+                                     'env-only lock-step loop (transition kernel + this kernel per lock-step); nothing subtracted' % launches}
         big.close()
         print(json.dumps(out), flush=True)
         if dist:

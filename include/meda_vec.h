@@ -104,6 +104,13 @@ int meda_vec_set_map(meda_vec *h, int which, const double *d_buf, void *stream);
  * out[3] = its (persistent) workgroup count. */
 int meda_vec_launch_shape(const meda_vec *h, int32_t out[4]);
 
+/* Measurement aid (no reference counterpart), as dmfb_vec_observe_timing: while enabled, every launch of the observation
+ * kernel carries a HIP event pair that receives the dispatch's own start and end time stamps -- the duration rocprofv3
+ * --kernel-trace reports.  _read waits for the timed launches (host-synchronising), returns their summed duration in
+ * microseconds and their count (at most 256 per read) and starts a new series. */
+int meda_vec_observe_timing(meda_vec *h, int enable);
+int meda_vec_observe_timing_read(meda_vec *h, double *total_us, int *launches);
+
 const char *meda_vec_strerror(int code);
 int meda_vec_last_hip_error(void);
 

@@ -105,7 +105,7 @@ MEDA_VEC_SYMBOLS = [
     'meda_vec_check_config', 'meda_vec_create', 'meda_vec_destroy', 'meda_vec_state_bytes', 'meda_vec_obs_len',
     'meda_vec_max_step', 'meda_vec_n_envs', 'meda_vec_n_agents', 'meda_vec_reset', 'meda_vec_restart',
     'meda_vec_set_task', 'meda_vec_get_task', 'meda_vec_step', 'meda_vec_observe', 'meda_vec_get_state',
-    'meda_vec_get_map', 'meda_vec_set_map', 'meda_vec_launch_shape', 'meda_vec_strerror', 'meda_vec_last_hip_error',
+    'meda_vec_get_map', 'meda_vec_set_map', 'meda_vec_launch_shape', 'meda_vec_observe_timing', 'meda_vec_observe_timing_read', 'meda_vec_strerror', 'meda_vec_last_hip_error',
 ]
 
 
@@ -132,6 +132,8 @@ def meda_vec():
     lib.meda_vec_get_map.argtypes = [vp, i32, vp, vp]
     lib.meda_vec_set_map.argtypes = [vp, i32, vp, vp]
     lib.meda_vec_launch_shape.argtypes = [vp, C.POINTER(C.c_int32 * 4)]
+    lib.meda_vec_observe_timing.argtypes = [vp, C.c_int]
+    lib.meda_vec_observe_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.meda_vec_strerror.argtypes = [i32]
     lib.meda_vec_strerror.restype = C.c_char_p
     lib.meda_vec_last_hip_error.argtypes = []

@@ -2,6 +2,7 @@
 // observation kernel, map/task/state accessors and the dispatch to the per-N kernels built from
 // meda_vec_n.hip.  Device code of the transition: meda_kernels.h.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdint>
@@ -409,6 +410,10 @@ struct meda_vec {
     int n_cu = 256;
     int8_t zoom_host[512];
     int8_t *zoom_dev = nullptr;
+    // meda_vec_observe_timing: event pairs that receive the dispatch time stamps of the observation kernel
+    static constexpr int kTimed = 256;
+    hipEvent_t ev[2 * kTimed] = {};
+    int timing = 0, timed = 0;
 };
 
 namespace {
@@ -432,12 +437,19 @@ int launch_step(meda_vec *h, const MStepArgs &a, hipStream_t s) { DISPATCH_N(h->
 int launch_reset(meda_vec *h, const uint8_t *m, int mode, hipStream_t s) { DISPATCH_N(h->cfg.n_agents, reset_n, h, m, mode, s) }
 
 int launch_observe(const meda_vec *h, const uint8_t *mask, int8_t *obs, hipStream_t s) {
-    const int T = h->dc.T;
-    (void)T;
     const dim3 grid(h->obs_grid), block(kObsBlock);
-    if (h->dc.n <= 4) LAUNCH(k_meda_observe<4>, grid, block, h->obs_lds, s, h->dc, h->dp, mask, obs);
-    else if (h->dc.n <= 8) LAUNCH(k_meda_observe<8>, grid, block, h->obs_lds, s, h->dc, h->dp, mask, obs);
-    else LAUNCH(k_meda_observe<MEDA_MAX_AGENTS>, grid, block, h->obs_lds, s, h->dc, h->dp, mask, obs);
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (h->timing && h->timed < meda_vec::kTimed) {
+        meda_vec *hm = const_cast<meda_vec *>(h);
+        t0 = hm->ev[2 * h->timed]; t1 = hm->ev[2 * h->timed + 1];
+        hm->timed += 1;
+    }
+    (void)hipGetLastError();
+    // hipExtLaunchKernelGGL: the events receive the dispatch's own start/end time stamps (nullptr = plain launch)
+    if (h->dc.n <= 4) hipExtLaunchKernelGGL(k_meda_observe<4>, grid, block, h->obs_lds, s, t0, t1, 0, h->dc, h->dp, mask, obs);
+    else if (h->dc.n <= 8) hipExtLaunchKernelGGL(k_meda_observe<8>, grid, block, h->obs_lds, s, t0, t1, 0, h->dc, h->dp, mask, obs);
+    else hipExtLaunchKernelGGL(k_meda_observe<MEDA_MAX_AGENTS>, grid, block, h->obs_lds, s, t0, t1, 0, h->dc, h->dp, mask, obs);
+    HIP_TRY(hipGetLastError());
     return MEDA_OK;
 }
 int launch_update_health(const meda_vec *h, hipStream_t s) {
@@ -550,6 +562,8 @@ int meda_vec_destroy(meda_vec *h) {
     DeviceGuard g(h->cfg.device);
     (void)hipFree(h->dp.st); (void)hipFree(h->dp.starts); (void)hipFree(h->dp.reset_flag);
     (void)hipFree(h->dp.health); (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage); (void)hipFree(h->zoom_dev);
+    for (int i = 0; i < 2 * meda_vec::kTimed; ++i)
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
     return MEDA_OK;
 }
@@ -658,6 +672,31 @@ int meda_vec_set_map(meda_vec *h, int which, const double *d_buf, void *stream) 
 int meda_vec_launch_shape(const meda_vec *h, int32_t out[4]) {
     if (!h || !out) return MEDA_ERR_BAD_ARG;
     out[0] = kBlock; out[1] = h->dc.T; out[2] = kObsBlock; out[3] = h->obs_grid;
+    return MEDA_OK;
+}
+
+int meda_vec_observe_timing(meda_vec *h, int enable) {
+    if (!h) return MEDA_ERR_BAD_ARG;
+    DeviceGuard g(h->cfg.device);
+    if (enable && !h->ev[0])
+        for (int i = 0; i < 2 * meda_vec::kTimed; ++i) HIP_TRY(hipEventCreate(&h->ev[i]));
+    h->timing = enable != 0;
+    h->timed = 0;
+    return MEDA_OK;
+}
+
+int meda_vec_observe_timing_read(meda_vec *h, double *total_us, int *launches) {
+    if (!h || !total_us || !launches) return MEDA_ERR_BAD_ARG;
+    DeviceGuard g(h->cfg.device);
+    double sum = 0.0;
+    for (int i = 0; i < h->timed; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(h->ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+        sum += (double)ms * 1e3;
+    }
+    *total_us = sum; *launches = h->timed;
+    h->timed = 0;
     return MEDA_OK;
 }
 

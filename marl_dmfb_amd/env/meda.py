@@ -160,6 +160,16 @@ class VecMEDA:
         _check(self.lib.meda_vec_launch_shape(self.h, C.byref(out)))
         return {'step_tile': out[0], 'observe_tile': out[1], 'observe_block': out[2], 'observe_workgroups': out[3]}
 
+    def observe_timing(self, enable):
+        """Start/stop collecting the dispatch time stamps of the observation kernel (meda_vec_observe_timing)."""
+        _check(self.lib.meda_vec_observe_timing(self.h, int(bool(enable))))
+
+    def observe_timing_read(self):
+        """(summed kernel duration in microseconds, launches) since the last read; synchronises the host."""
+        us, n = C.c_double(0.0), C.c_int(0)
+        _check(self.lib.meda_vec_observe_timing_read(self.h, C.byref(us), C.byref(n)))
+        return us.value, n.value
+
     def get_state(self):
         E, n, dev = self.n_envs, self.n_agents, self.device
         pos = torch.empty((E, n, 2), dtype=torch.int32, device=dev)

@@ -20,6 +20,8 @@ CFGS = {
     # and the CLI default chip instead
     'M30': dict(width=30, length=30, n_agents=4, fov=19, meda=True),
     'M60': dict(width=30, length=60, n_agents=4, fov=19, meda=True),
+    # MEDAEnv_v0_2 observation (3 int8 layers + zoomed direction): what the MEDA training path uses
+    'M30v2': dict(width=30, length=30, n_agents=4, fov=19, meda=True, version=2),
 }
 
 
@@ -27,7 +29,7 @@ def algo_bytes(cfg, ext_uniforms=False):
     """algorithmic bytes per env-step."""
     n, fov = cfg['n_agents'], cfg['fov']
     if cfg.get('meda'):
-        return n * (4 * fov * fov + 2) + 8 * n + n + 9 + n + 2 * (4 * n + 16)
+        return n * ((3 if cfg.get('version') == 2 else 4) * fov * fov + 2) + 8 * n + n + 9 + n + 2 * (4 * n + 16)
     writes = n * (3 * fov * fov + 2) + 8 * n + n + 5
     reads = n + (8 * n if ext_uniforms else 0) + (8 * n if cfg.get('b_degrade') else 0)
     state = 2 * (2 * n + n + 8) + (4 * n if cfg.get('b_degrade') else 0)
@@ -42,9 +44,10 @@ def launch_labels(name, cfg, env, E):
     sh = env.launch_shape()
     out = {}
     if cfg['meda']:
-        ob = n * (4 * fov * fov + 2)
-        out['medak::k_meda_step<%d>|%d' % (n, wgs(sh['step_tile']))] = {'key': 'k_meda_step_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (algo_bytes(cfg) - ob) * E}
-        out['(anonymous namespace)::k_meda_observe<%d>|%d' % (4 if n <= 4 else 8 if n <= 8 else 16, sh['observe_workgroups'] * sh['observe_block'])] = {'key': 'k_meda_observe_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (ob + 5 * n + 8) * E}
+        vtag = '_v0_2' if cfg.get('version') == 2 else ''
+        ob = n * ((3 if cfg.get('version') == 2 else 4) * fov * fov + 2)
+        out['medak::k_meda_step<%d>|%d' % (n, wgs(sh['step_tile']))] = {'key': 'k_meda_step%s_%dx%d_%dd_E%d' % (vtag, W, L, n, E), 'algo_bytes': (algo_bytes(cfg) - ob) * E}
+        out['(anonymous namespace)::k_meda_observe<%d>|%d' % (4 if n <= 4 else 8 if n <= 8 else 16, sh['observe_workgroups'] * sh['observe_block'])] = {'key': 'k_meda_observe%s_%dx%d_%dd_E%d' % (vtag, W, L, n, E), 'algo_bytes': (ob + 5 * n + 8) * E}
         return out
     ob = n * (3 * fov * fov + 2)
     maps = 'true' if cfg.get('b_degrade') else 'false'
@@ -71,6 +74,8 @@ def run(name, E, iters, autoreset=True, observe=False, labels=None):
         env.step(acts[i % 8], autoreset=autoreset)
     torch.cuda.synchronize()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if observe:
+        env.observe_timing(True)   # dispatch time stamps of the observation launches inside the lock-step loop
     t0.record()
     for i in range(iters):
         env.step(acts[i % 8], autoreset=autoreset)
@@ -80,7 +85,12 @@ def run(name, E, iters, autoreset=True, observe=False, labels=None):
     b = algo_bytes(cfg)
     out = dict(cfg=name, E=E, us_per_launch=round(ms * 1e3, 2), env_steps_per_s=round(E / ms * 1e3),
                algo_bytes_per_env_step=b, algo_GBps=round(E * b / ms / 1e6, 1), frac_of_8TBps=round(E * b / ms / 1e6 / 8000, 4))
-    if observe:  # the FOV-gather kernel alone, back-to-back launches
+    if observe:
+        # the FOV-gather kernel alone: the dispatch time stamps of its launches inside the lock-step loop above (what
+        # rocprofv3 --kernel-trace reports); at batches where the transition and the observation are ONE fused launch
+        # there is no such launch and the standalone kernel is timed back to back instead
+        us_in_loop, launches = env.observe_timing_read()
+        env.observe_timing(False)
         env.observe()
         torch.cuda.synchronize()
         t0.record()
@@ -88,17 +98,19 @@ def run(name, E, iters, autoreset=True, observe=False, labels=None):
             env.observe()
         t1.record()
         torch.cuda.synchronize()
-        ms = t0.elapsed_time(t1) / iters
+        b2b = t0.elapsed_time(t1) / iters * 1e3
+        us = us_in_loop / launches if launches else b2b
         n, fov = cfg['n_agents'], cfg['fov']
-        fb = n * ((4 if meda else 3) * fov * fov + 2) + 5 * n + 8
-        out['observe'] = dict(us_per_launch=round(ms * 1e3, 2), algo_bytes_per_env=fb, algo_GBps=round(E * fb / ms / 1e6, 1),
-                              frac_of_8TBps=round(E * fb / ms / 1e6 / 8000, 4))
+        fb = n * (((3 if cfg.get('version') == 2 else 4) if meda else 3) * fov * fov + 2) + 5 * n + 8
+        out['observe'] = dict(us_per_launch=round(us, 2), timing='dispatch time stamps in the lock-step loop' if launches else 'back-to-back launches',
+                              back_to_back_us_per_launch=round(b2b, 2), algo_bytes_per_env=fb, algo_GBps=round(E * fb / us / 1e3, 1),
+                              frac_of_8TBps=round(E * fb / us / 1e3 / 8000, 4))
     return out
 
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('--cfg', default='A,D,E,M30,M60')
+    ap.add_argument('--cfg', default='A,D,E,M30,M60,M30v2')
     ap.add_argument('--sizes', default='4096,65536,262144,1048576')
     ap.add_argument('--msizes', default=None, help='batch sizes for the MEDA configurations (default: --sizes up to 65536)')
     ap.add_argument('--iters', type=int, default=200)

@@ -24,20 +24,21 @@ python3 $REPO/tools/reduce_profiles.py trace $OUT/bench_trace $SUM/bench_kernels
 cp $(ls $OUT/bench_trace/*/*_kernel_stats.csv | head -1) $SUM/bench_kernel_stats.csv
 
 echo "== env tiers (plain) ==" ; date
-python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60 --sizes 4096,65536,262144 --iters 100 --observe > $SUM/env_tiers.jsonl
+python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 --sizes 4096,65536,262144 --iters 100 --observe > $SUM/env_tiers.jsonl
 cat $SUM/env_tiers.jsonl
 
 echo "== env kernels under rocprofv3 --kernel-trace ==" ; date
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/env_trace -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60 \
-    --sizes 4096,262144 --msizes 4096,65536 --iters 40 --observe > $OUT/env_trace.log 2>&1
-python3 $REPO/tools/reduce_profiles.py trace $OUT/env_trace $SUM/env_kernels_by_grid.csv '(dmfbk|medak)::'
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/env_trace -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 \
+    --sizes 4096,262144 --msizes 65536 --iters 40 --observe > $OUT/env_trace.log 2>&1
+python3 $REPO/tools/reduce_profiles.py trace $OUT/env_trace $SUM/env_kernels_by_grid.csv '(dmfbk|medak)::|k_meda_observe'
 
 echo "== HBM traffic counters ==" ; date
-# sizes 4096 + 262144 (MEDA: 4096 + 65536) only: the fused 4096-chip launch and the 65536-chip step-only launch share a grid size
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60 \
-    --sizes 4096,262144 --msizes 4096,65536 --iters 24 --observe --labels $OUT/labels.json > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60 \
-    --sizes 4096,262144 --msizes 4096,65536 --iters 24 --observe > $OUT/pmc_write.log 2>&1
+# sizes 4096 + 262144 (MEDA: 65536) only: the fused 4096-chip launch and the 65536-chip step-only launch share a grid size,
+# and so do the persistent MEDA observation launches of all batch sizes
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 \
+    --sizes 4096,262144 --msizes 65536 --iters 24 --observe --labels $OUT/labels.json > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 \
+    --sizes 4096,262144 --msizes 65536 --iters 24 --observe > $OUT/pmc_write.log 2>&1
 python3 $REPO/tools/reduce_profiles.py traffic $OUT/pmc_fetch $OUT/pmc_write $SUM/traffic.json $OUT/labels.json
 echo "== write-pattern and counter-calibration probes ==" ; date
 if [ -x $REPO/tools/probe/write_probe_bin ]; then
