@@ -19,6 +19,7 @@
 
 #include "../../include/crnn_ops.h"
 #include "crnn_mfma.h"
+#include "crnn_mfma19.h"
 
 namespace {
 
@@ -412,6 +413,27 @@ int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const
 }
 
 template <int OD>
+int launch19(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w3, const float *b3,
+             float *out, long out_stride, const int8_t *onehot, int n_actions, const float *mlp_w, const float *mlp_b, hipStream_t s) {
+    using GM = crnn_mfma19::Geo<OD>;
+    const size_t lds = GM::LDS_FLOATS * sizeof(float);
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
+        hipError_t e = hipFuncSetAttribute((const void *)crnn_mfma19::k_conv19_mfma<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
+        attr_set.mark();
+    }
+    const long n_blocks = (rows + GM::RB - 1) / GM::RB;
+    const int grid = (int)(n_blocks < 256 ? n_blocks : 256);  // persistent: one workgroup per CU keeps the weights in registers
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((crnn_mfma19::k_conv19_mfma<OD>), dim3(grid), dim3(crnn_mfma19::kBlockM), lds, s, obs, obs_stride, rows, w1, b1, w3,
+                       b3, out, out_stride, onehot, n_actions, mlp_w, mlp_b);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
+    return CRNN_OK;
+}
+
+template <int OD>
 int launch_bwd(const int8_t *obs, long obs_stride, long rows, const float *a2, long a2_stride,
                const float *g, long g_stride, const float *w2, float *part, int grid, float *grads, const float *w1, const float *b1,
                hipStream_t s) {
@@ -456,6 +478,19 @@ int crnn_front9_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d
     if (rows == 0) return CRNN_OK;
     if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
     if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
+    return CRNN_ERR_UNSUPPORTED;
+}
+
+int crnn_front19_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
+                         const float *d_w1, const float *d_b1, const float *d_w3, const float *d_b3, const float *d_mlp_w,
+                         const float *d_mlp_b, int od, float *d_out, int64_t out_stride, void *stream) {
+    const bool vec = d_mlp_w != nullptr;
+    if (!d_obs || !d_w1 || !d_b1 || !d_w3 || !d_b3 || !d_out || rows < 0 || obs_stride < 3 * 19 * 19 + (vec ? 2 : 0) ||
+        out_stride < od * 25 + (vec ? 10 : 0) || n_actions < 0 || n_actions > 16 || (vec && !d_mlp_b))
+        return CRNN_ERR_BAD_ARG;
+    if (rows == 0) return CRNN_OK;
+    if (od == 24) return launch19<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w3, d_b3, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
+    if (od == 32) return launch19<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w3, d_b3, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
 }
 

@@ -383,11 +383,17 @@ class CRNN(nn.Module):
         R = obs_i8.shape[0]
         out = torch.empty((R, self.out), dtype=torch.float32, device=obs_i8.device)
         c1, c2 = self.convs[0], self.convs[1]
-        rc = lib.crnn_conv9_forward(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), R,
-                                    C.c_void_p(c1.weight.data_ptr()), C.c_void_p(c1.bias.data_ptr()),
-                                    C.c_void_p(c2.weight.data_ptr()), C.c_void_p(c2.bias.data_ptr()),
-                                    c1.out_channels, C.c_void_p(out.data_ptr()), out.stride(0),
-                                    C.c_void_p(torch.cuda.current_stream(obs_i8.device).cuda_stream))
+        stream = C.c_void_p(torch.cuda.current_stream(obs_i8.device).cuda_stream)
+        if self._hip_geometry() == 19:  # pixel features only: no vector branch (NULL mlp pointers)
+            rc = lib.crnn_front19_forward(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), None, 0, R,
+                                          C.c_void_p(c1.weight.data_ptr()), C.c_void_p(c1.bias.data_ptr()),
+                                          C.c_void_p(c2.weight.data_ptr()), C.c_void_p(c2.bias.data_ptr()), None, None,
+                                          c1.out_channels, C.c_void_p(out.data_ptr()), out.stride(0), stream)
+        else:
+            rc = lib.crnn_conv9_forward(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), R,
+                                        C.c_void_p(c1.weight.data_ptr()), C.c_void_p(c1.bias.data_ptr()),
+                                        C.c_void_p(c2.weight.data_ptr()), C.c_void_p(c2.bias.data_ptr()),
+                                        c1.out_channels, C.c_void_p(out.data_ptr()), out.stride(0), stream)
         if rc != 0:
             raise RuntimeError('crnn_conv9_forward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
         return out
@@ -406,14 +412,16 @@ class CRNN(nn.Module):
         if onehot_i8 is not None:
             onehot_i8 = onehot_i8.to(torch.int8).contiguous()
             oh = C.c_void_p(onehot_i8.data_ptr())
-        rc = lib.crnn_front9_forward(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), oh, self.n_actions, R,
+        # fov 19 (MEDA v0_2): stride-2 conv, then the tied conv3 twice (include/crnn_ops.h: crnn_front19_forward)
+        fn = lib.crnn_front19_forward if self._hip_geometry() == 19 else lib.crnn_front9_forward
+        rc = fn(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), oh, self.n_actions, R,
                                      C.c_void_p(c1.weight.data_ptr()), C.c_void_p(c1.bias.data_ptr()),
                                      C.c_void_p(c2.weight.data_ptr()), C.c_void_p(c2.bias.data_ptr()),
                                      C.c_void_p(self.mlp1.weight.data_ptr()), C.c_void_p(self.mlp1.bias.data_ptr()),
                                      c1.out_channels, C.c_void_p(out.data_ptr()), out.stride(0),
                                      C.c_void_p(torch.cuda.current_stream(obs_i8.device).cuda_stream))
         if rc != 0:
-            raise RuntimeError('crnn_front9_forward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
+            raise RuntimeError('crnn_front%d_forward failed: %d (hip %d)' % (self._hip_geometry(), rc, lib.crnn_last_hip_error()))
         return out
 
     def features_obs_train(self, obs_i8, la_rows):
@@ -432,9 +440,19 @@ class CRNN(nn.Module):
                 and self.input_dim[:3] == (3, 9, 9) and len(self.convs) == 2 and self.convs[0].out_channels in (24, 32)
                 and self.convs[0] is not self.convs[1])
 
+    def _hip_geometry(self):
+        """9 / 19: the conv stack is one of the two the HIP front-end kernels implement (conv_str(9): conv1, conv3;
+        conv_str(19): stride-2 conv, then the SAME conv3 module twice); None otherwise."""
+        cv = self.convs
+        if self.input_dim[:3] == (3, 9, 9) and len(cv) == 2 and cv[0] is not cv[1] and cv[0].stride[0] == 1:
+            return 9
+        if self.input_dim[:3] == (3, 19, 19) and len(cv) == 3 and cv[1] is cv[2] and cv[0].stride[0] == 2 and cv[1].stride[0] == 1:
+            return 19
+        return None
+
     def _hip_conv_ok(self, obs_i8):
         return (self.conv_impl == 'gemm' and obs_i8.is_cuda and obs_i8.dtype == torch.int8 and not torch.is_grad_enabled()
-                and self.input_dim[:3] == (3, 9, 9) and len(self.convs) == 2 and self.convs[0].out_channels in (24, 32)
+                and self._hip_geometry() is not None and self.convs[0].out_channels in (24, 32)
                 and self.convs[0].weight.is_contiguous() and self.convs[1].weight.is_contiguous())
 
     def act_ok(self, obs_i8):

@@ -47,6 +47,61 @@ def test_conv9_forward_matches_torch(od, rows):
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
 
 
+def _args19(od, n_actions=9):
+    return types.SimpleNamespace(obs_shape=(3, 19, 19, 2, 1085), hyper_hidden_dim=od, rnn_hidden_dim=128, n_actions=n_actions, fov=19)
+
+
+@pytest.mark.parametrize('od,rows', [(32, 16384), (24, 4099), (32, 7), (24, 1), (32, 8), (32, 9)])
+def test_front19_pixel_features_match_torch(od, rows):
+    """fov 19 (MEDA v0_2): stride-2 conv + the tied conv3 twice (base_net.py:23-33), pixel features only, against
+    conv2d+ReLU three times on the CPU.  Floating point: rtol 1e-5, atol 1e-5 (same products, other summation order)."""
+    from marl_dmfb_amd.network.base_net import CRNN
+    torch.manual_seed(od + rows)
+    net = CRNN(_args19(od)).cuda()
+    assert net.convs[1] is net.convs[2] and net._hip_geometry() == 19
+    obs = torch.randint(0, 13, (rows, 1085), dtype=torch.int8, device='cuda')   # layer values: droplet index + 1
+    with torch.no_grad():
+        got = net._pixel_features_hip(obs)
+        ref = obs[:, :1083].float().view(rows, 3, 19, 19).cpu()
+        for conv in net.convs:
+            ref = torch.relu(torch.nn.functional.conv2d(ref, conv.weight.cpu(), conv.bias.cpu(), stride=conv.stride))
+        ref = ref.reshape(rows, -1)
+    assert got.shape == (rows, od * 25)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('od,rows,strided', [(32, 4096 * 4, False), (24, 1001, True), (32, 3, False)])
+def test_front19_forward_obs_matches_reference_forward(od, rows, strided):
+    """The whole rollout forward for fov 19 (HIP front end incl. the vector branch, then GRU cell and head) against the
+    reference-shaped CPU forward on float inputs; also with a row stride larger than the row (a slice of a wider buffer)
+    and with negative direction bytes."""
+    from marl_dmfb_amd.network.base_net import CRNN
+    a = _args19(od)
+    torch.manual_seed(rows)
+    net = CRNN(a).cuda()
+    if strided:
+        wide = torch.randint(0, 6, (rows, 1100), dtype=torch.int8, device='cuda')
+        obs = wide[:, 3:1088]
+    else:
+        obs = torch.randint(0, 6, (rows, 1085), dtype=torch.int8, device='cuda')
+    obs[:, 1083:] = torch.randint(-30, 31, (rows, 2), dtype=torch.int8, device='cuda')
+    la = torch.nn.functional.one_hot(torch.randint(0, 9, (rows,), device='cuda'), 9).to(torch.int8)
+    h = torch.randn(rows, 128, device='cuda')
+    with torch.no_grad():
+        assert net.act_ok(obs) if not strided else True
+        x = net._front_features_hip(obs, la)
+        q1, h1 = net.forward_obs(obs, la, h)
+    cpu = CRNN(a)
+    cpu.load_state_dict(net.state_dict())
+    with torch.no_grad():
+        inp = torch.cat([obs.float(), la.float()], dim=1).cpu()
+        xr = cpu.features(inp)
+        q2, h2 = cpu(inp, h.cpu())
+    np.testing.assert_allclose(x.cpu().numpy(), xr.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(q1.cpu().numpy(), q2.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(h1.cpu().numpy(), h2.numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_forward_obs_uses_kernel_and_matches_reference_forward():
     from marl_dmfb_amd.network.base_net import CRNN
     a = types.SimpleNamespace(obs_shape=(3, 9, 9, 2, 245), hyper_hidden_dim=24, rnn_hidden_dim=128, n_actions=5, fov=9)
