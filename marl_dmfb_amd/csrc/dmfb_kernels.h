@@ -50,6 +50,7 @@ struct DevCfg {
     uint32_t fov_magic;  // ceil(2^32 / fov): k / fov == __umulhi(k, fov_magic) for the ranges used (fov >= 2)
     int nq;              // 8-byte words per band image, padded to a multiple of 12 (see DevPtrs::band)
     int ucap;            // steps a chip's usage log holds (= max_step), see DevPtrs::ulog
+    int lstride;         // uint16 entries per logged step: 16 (one aligned 32-byte sector per step, unused ones 0xFFFF)
     int hist_bytes;      // LDS bytes of one wave's usage histogram, 0 = chip too large for LDS (global-atomic path)
     int compact;         // 1: the maps are the generator's own (never replaced through set_map): the transition may rebuild a
                          // cell's health from DevPtrs::kmap instead of gathering the float64 map (see health_of)
@@ -63,14 +64,17 @@ struct DevPtrs {
     double *degrade;   // [E][W*L]
     uint16_t *usage;   // [E][W*L]
     // addUsage (dmfb.py:459-463) as an append-only log: step k of a chip since its last flush stores, per droplet, the cell
-    // index x*L+y it occupies (0xFFFF: the droplet is on its goal) at ulog[(e*ucap + k)*n + i].  A transition writes 2n
-    // contiguous bytes instead of n read-modify-writes scattered over a 64/128-byte sector each; the log is folded into the
-    // usage map (flush_usage) when the episode is reset, when it is full, and before the map is read or written from outside.
+    // index x*L+y it occupies (0xFFFF: the droplet is on its goal, or the slot is beyond n) at ulog[(e*ucap + k)*16 + i].
+    // A transition writes ONE aligned 32-byte sector instead of n read-modify-writes scattered over a sector each (and no
+    // partial-sector write, which HBM3 turns into a read-modify-write); the log is folded into the usage map (flush_usage)
+    // when the episode is reset, when it is full, and before the map is read or written from outside.
     uint16_t *ulog;
-    // How often updateHealth (dmfb.py:465-471) has degraded each cell since the maps were generated, saturating at 255:
-    // uint8 [E][W*L].  m_health[cell] is then 1.0 multiplied `k` times by m_degrade[cell] -- the very products the reference
-    // forms -- and m_degrade[cell] is a pure function of the Philox key (gen_degrade_env), so a transition can read one
-    // BYTE per droplet (a chip's whole map is a few 128-byte lines) instead of one float64 from a 128-byte line each.
+    // How often updateHealth (dmfb.py:465-471) has degraded each cell since the maps were generated, saturating at 15:
+    // 4 bits per cell, [E][kmap_bytes(W*L)] (cell c = nibble c & 1 of byte c >> 1).  m_health[cell] is then 1.0 multiplied
+    // `k` times by m_degrade[cell] -- the very products the reference forms -- and m_degrade[cell] is a pure function of
+    // the Philox key (gen_degrade_env), so a transition reads one byte per droplet out of a map of W*L/2 bytes (a 20x20
+    // chip: 200 bytes, under two 128-byte lines) instead of one float64 from a 128-byte line each.  A saturated count
+    // (health <= 0.6^15 of a degrading cell, or 15+ degradations) falls back to the float64 map for that cell.
     uint8_t *kmap;
     const int8_t *zoom;  // [2][511] direction zoom table
     uint32_t *blocks;    // [n_blocks][E] x_min | x_max<<8 | y_min<<16 | y_max<<24, or nullptr
@@ -316,6 +320,18 @@ __device__ __forceinline__ double degrade_of(const DevCfg &c, uint32_t env_gid, 
     const double d = u53(w[0], w[1]) * 0.4 + 0.6;
     return (u53(w[2], w[3]) < c.per_healthy) ? 1.0 : d;
 }
+constexpr int kCountMax = 15;  // saturation value of a degrade count (4 bits)
+__host__ __device__ inline size_t kmap_bytes(size_t cells) { return ((cells + 1) / 2 + 3) & ~(size_t)3; }  // per chip, whole 32-bit words
+__device__ __forceinline__ int kmap_get(const DevPtrs &p, size_t kb, int e, int cell) {
+    return (p.kmap[(size_t)e * kb + (cell >> 1)] >> (4 * (cell & 1))) & kCountMax;
+}
+// count of one cell + 1 (the caller's lane is the only writer of this nibble; the other seven nibbles of the word may
+// belong to other lanes of the wave: 32-bit atomic add, no carry because the nibble is below 15)
+__device__ __forceinline__ void kmap_bump(const DevPtrs &p, size_t kb, int e, int cell) {
+    if (kmap_get(p, kb, e, cell) == kCountMax) return;
+    const size_t byte = (size_t)e * kb + (cell >> 1);
+    atomicAdd((uint32_t *)p.kmap + (byte >> 2), 1u << (8 * (byte & 3) + 4 * (cell & 1)));
+}
 __device__ __forceinline__ double health_from_count(double d, int k) {
     double h = 1.0;
     for (int t = 0; t < k; ++t) h = h * d;  // the reference's products, in its order (dmfb.py:469)
@@ -338,9 +354,9 @@ __device__ __forceinline__ void gen_degrade_env(const DevCfg &c, const DevPtrs &
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 __device__ __forceinline__ void flush_usage(const DevCfg &c, const DevPtrs &p, int e, int ulen, bool update, uint16_t *hist, int lane) {
     const int cells = c.W * c.L;
-    const size_t base = (size_t)e * cells;
-    const uint16_t *log = p.ulog + (size_t)e * c.ucap * c.n;
-    const int entries = ulen * c.n;
+    const size_t base = (size_t)e * cells, kb = kmap_bytes(cells);
+    const uint16_t *log = p.ulog + (size_t)e * c.ucap * c.lstride;
+    const int entries = ulen * c.lstride;
     if (hist) {
         uint32_t *h32 = (uint32_t *)hist;
         for (int k = lane; k < cells; k += kWave) hist[k] = p.usage[base + k];
@@ -354,8 +370,7 @@ __device__ __forceinline__ void flush_usage(const DevCfg &c, const DevPtrs &p, i
             uint16_t u = hist[k];
             if (update && u > 50) {
                 p.health[base + k] = p.health[base + k] * p.degrade[base + k];
-                const uint8_t cnt = p.kmap[base + k];
-                if (cnt != 255) p.kmap[base + k] = (uint8_t)(cnt + 1);
+                kmap_bump(p, kb, e, k);
                 u = 0;
             }
             p.usage[base + k] = u;
@@ -378,8 +393,7 @@ __device__ __forceinline__ void flush_usage(const DevCfg &c, const DevPtrs &p, i
         const uint32_t w = __hip_atomic_load(&u32[g >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not through this CU's L1
         if (((w >> (16 * (g & 1))) & 0xffffu) > 50) {
             p.health[g] = p.health[g] * p.degrade[g];
-            const uint8_t cnt = p.kmap[g];
-            if (cnt != 255) p.kmap[g] = (uint8_t)(cnt + 1);
+            kmap_bump(p, kb, e, k);
             atomicAnd(&u32[g >> 1], (g & 1) ? 0x0000ffffu : 0xffff0000u);  // the neighbouring cell may belong to another lane
         }
     }
@@ -650,6 +664,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
             const bool use_draws = MAPS || a.uniforms != nullptr;
             const bool compact = MAPS && c.compact;
             uint8_t kcnt[N];
+
             if (use_draws) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
@@ -657,15 +672,21 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
                     kcnt[i] = 0;
                     // getMoveProb (dmfb.py:361-363): the float64 map, or one byte of the degrade-count map
                     if (MAPS && !compact) prob[i] = p.health[(size_t)e * cells + r.x[i] * c.L + r.y[i]];
-                    if (compact) kcnt[i] = p.kmap[(size_t)e * cells + r.x[i] * c.L + r.y[i]];
+#ifndef DMFB_ABLATE_KMAP  // DMFB_ABLATE_*: timing experiments only (tools/build_variant.sh with EXTRA_FLAGS): wrong results
+                    if (compact) kcnt[i] = (uint8_t)kmap_get(p, kmap_bytes(cells), e, r.x[i] * c.L + r.y[i]);
+#endif
                     if (a.uniforms) draw[i] = a.uniforms[a0 + i];
                 }
                 if (!a.uniforms) {
 #pragma unroll
                     for (int i = 0; i < N; ++i) {
+#ifdef DMFB_ABLATE_PHILOX
+                        draw[i] = (double)((r.rstep * 2654435761u + (uint32_t)i * 40503u) >> 8) * (1.0 / 16777216.0);
+#else
                         uint32_t w[4];
                         philox(c.k0, c.k1, c.env_id0 + (uint32_t)e, r.rstep, (uint32_t)i, STREAM_MOVE << 8, w);
                         draw[i] = u53(w[0], w[1]);
+#endif
                     }
                 }
                 if (compact) {  // health = 1.0 * degrade * ... * degrade (count times), degrade from the map's Philox stream
@@ -673,7 +694,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
 #pragma unroll
                     for (int i = 0; i < N; ++i) {
                         const int cell = r.x[i] * c.L + r.y[i];
-                        if (kcnt[i] == 255) prob[i] = p.health[(size_t)e * cells + cell];  // saturated count: the map itself
+                        if (kcnt[i] == kCountMax) prob[i] = p.health[(size_t)e * cells + cell];  // saturated count: the map itself
                         else if (kcnt[i] != 0) prob[i] = health_from_count(degrade_of(c, c.env_id0 + (uint32_t)e, gen, cell), kcnt[i]);
                     }
                 }
@@ -772,10 +793,26 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
             }
             bool log_full = false;
             if (MAPS && (a.flags & DMFB_STEP_RECORD)) {  // addUsage (dmfb.py:459-463): append this step to the chip's usage log
-                uint16_t *ul = p.ulog + ((size_t)e * c.ucap + r.ulen) * N;
+                uint16_t *ul = p.ulog + ((size_t)e * c.ucap + r.ulen) * c.lstride;
+#ifndef DMFB_ABLATE_LOG
+                if (c.lstride == 16) {  // one whole, aligned 32-byte sector per step: no partial-sector write reaches HBM
+                    uint32_t w[8];
 #pragma unroll
-                for (int i = 0; i < N; ++i)
-                    ul[i] = (iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) != 0 ? (uint16_t)(r.x[i] * c.L + r.y[i]) : (uint16_t)0xffff;
+                    for (int k = 0; k < 8; ++k) {
+                        uint32_t lo = 0xffffu, hi = 0xffffu;
+                        if (2 * k < N && (iabs(r.x[2 * k] - r.gx[2 * k]) + iabs(r.y[2 * k] - r.gy[2 * k])) != 0) lo = (uint32_t)(r.x[2 * k] * c.L + r.y[2 * k]);
+                        if (2 * k + 1 < N && (iabs(r.x[2 * k + 1] - r.gx[2 * k + 1]) + iabs(r.y[2 * k + 1] - r.gy[2 * k + 1])) != 0)
+                            hi = (uint32_t)(r.x[2 * k + 1] * c.L + r.y[2 * k + 1]);
+                        w[k] = lo | (hi << 16);
+                    }
+                    ((uint4 *)ul)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+                    ((uint4 *)ul)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        ul[i] = (iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) != 0 ? (uint16_t)(r.x[i] * c.L + r.y[i]) : (uint16_t)0xffff;
+                }
+#endif
                 r.ulen += 1;
                 log_full = (int)r.ulen == c.ucap;  // folded into the map right after this step: a step always finds room
             }
@@ -843,6 +880,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
             }
         }
         if (active) store_env<N>(p, E, e, r, ended);
+
         if (present) {
             if (want_obs) {
 #pragma unroll
@@ -1056,7 +1094,9 @@ __global__ __launch_bounds__(kBlock) void k_reset(DevCfg c, DevPtrs p, const uin
             flush_usage(c, p, e, ulen, true, hist, lane);
         } else {  // new maps: whatever the log holds is discarded with the old usage map
             const size_t base = (size_t)e * cells;
-            for (int cidx = lane; cidx < cells; cidx += kWave) { p.health[base + cidx] = 1.0; p.usage[base + cidx] = 0; p.kmap[base + cidx] = 0; }
+            for (int cidx = lane; cidx < cells; cidx += kWave) { p.health[base + cidx] = 1.0; p.usage[base + cidx] = 0; }
+            const size_t kb = kmap_bytes(cells);
+            for (int w = lane; w < (int)(kb / 4); w += kWave) ((uint32_t *)p.kmap)[((size_t)e * kb) / 4 + w] = 0u;
             gen_degrade_env(c, p, cells, e, rmap, lane, kWave);
         }
     }

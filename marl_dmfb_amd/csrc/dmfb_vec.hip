@@ -347,11 +347,13 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
         CREATE_TRY(hipMalloc(&h->dp.degrade, cells * E * 8));
         CREATE_TRY(hipMalloc(&h->dp.usage, cells * E * 2 + 4));  // + 4: the 32-bit atomics of the large-chip path stay in bounds
         d.ucap = d.max_step;
-        CREATE_TRY(hipMalloc(&h->dp.ulog, (size_t)E * d.ucap * n * 2));
-        CREATE_TRY(hipMalloc(&h->dp.kmap, cells * E));
+        d.lstride = 16;
+        if (const char *v = getenv("DMFB_VEC_LOG_STRIDE")) d.lstride = atoi(v) == 16 ? 16 : n;  // measurement knob: n = packed entries
+        CREATE_TRY(hipMalloc(&h->dp.ulog, (size_t)E * d.ucap * d.lstride * 2));
+        CREATE_TRY(hipMalloc(&h->dp.kmap, kmap_bytes(cells) * E));
         d.compact = 1;  // until health or degrade is replaced through dmfb_vec_set_map
         d.hist_bytes = (int)cells <= kHistMaxCells ? (int)((cells * 2 + 15) & ~(size_t)15) : 0;
-        h->bytes += cells * E * 19 + (size_t)E * d.ucap * n * 2;
+        h->bytes += cells * E * 18 + kmap_bytes(cells) * E + (size_t)E * d.ucap * d.lstride * 2;
     }
     // GenRandomBlocks guards (dmfb.py:230-234): no blocks on tiny chips or above 20 % coverage
     d.nb = cfg->n_blocks;

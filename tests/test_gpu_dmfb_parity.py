@@ -308,27 +308,34 @@ def test_lockstep_E_generator_maps_compact_health_path():
               greedy=0.7, explicit_health=False)
 
 
-def test_degrade_count_saturates_at_255():
-    """More than 255 degradations of a cell: the byte count saturates and the transition falls back to the float64 map."""
-    cfg = dict(width=10, length=10, n_agents=4, fov=9, b_degrade=True, per_degrade=1.0)
-    E, seed = 12, 35
-    O = DmfbOracle(n_envs=E, seed=seed, **cfg)
-    V = _vec(n_envs=E, seed=seed, **cfg)
-    over = np.full((E, 10, 10), 60.0)
-    for k in range(262):                 # every reset degrades every cell once (usage 60 > 50)
-        for B in (O, V):
-            B.set_map('usage', over)
-            B.reset()
-    np.testing.assert_array_equal(_bits(O.get_map('health')), _bits(V.get_map('health')))
-    rng = np.random.default_rng(seed)
-    assert O.get_map('health').max() < 1.0
-    for t in range(60):
-        a = rng.integers(0, 5, (E, 4)).astype(np.int32)
-        ro, do, co, so = O.step(a)
-        rv, dv, cv, sv = V.step(a)
-        np.testing.assert_array_equal(_bits(ro), _bits(rv), err_msg='rewards t=%d' % t)
-        np.testing.assert_array_equal(O.get_state()['pos'], V.get_state()['pos'], err_msg='pos t=%d' % t)
-    np.testing.assert_array_equal(O.observe(), V.observe())
+def test_degrade_count_saturation():
+    """The 4-bit degrade counts saturate at 15: up to 14 degradations of a cell the transition rebuilds its health from
+    the count, from 15 on it falls back to the float64 map.  Parity is checked on both sides of the boundary and far
+    beyond it (262 degradations), with odd cell counts too (two cells share a byte, eight a word)."""
+    for cfg, E, seed in ((dict(width=10, length=10, n_agents=4, fov=9, b_degrade=True, per_degrade=1.0), 12, 35),
+                         (dict(width=9, length=7, n_agents=3, fov=5, b_degrade=True, per_degrade=0.8), 7, 36)):
+        O = DmfbOracle(n_envs=E, seed=seed, **cfg)
+        V = _vec(n_envs=E, seed=seed, **cfg)
+        n = cfg['n_agents']
+        rng = np.random.default_rng(seed)
+        over = np.full((E, cfg['width'], cfg['length']), 60.0)
+        over[:, ::2, 1::3] = 10.0        # a third of the cells is not degraded: neighbouring nibbles differ
+        done = 0
+        for target in (13, 14, 15, 16, 17, 262):
+            while done < target:         # every reset degrades the marked cells once (usage 60 > 50)
+                for B in (O, V):
+                    B.set_map('usage', over)
+                    B.reset()
+                done += 1
+            np.testing.assert_array_equal(_bits(O.get_map('health')), _bits(V.get_map('health')), err_msg='health after %d' % done)
+            for t in range(25):
+                a = rng.integers(0, 5, (E, n)).astype(np.int32)
+                ro, do, co, so = O.step(a)
+                rv, dv, cv, sv = V.step(a)
+                np.testing.assert_array_equal(_bits(ro), _bits(rv), err_msg='rewards after %d t=%d' % (done, t))
+                np.testing.assert_array_equal(O.get_state()['pos'], V.get_state()['pos'], err_msg='pos after %d t=%d' % (done, t))
+            np.testing.assert_array_equal(O.observe(), V.observe())
+        assert O.get_map('health').max() == 1.0 and O.get_map('health').min() < 0.7 ** 15
 
 
 @pytest.mark.parametrize('cfg,E', [(A, 150001), (D, 40003)], ids=['A', 'D'])

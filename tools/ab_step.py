@@ -17,6 +17,10 @@ CFGS = {'A': dict(width=10, length=10, n_agents=4, fov=9), 'D': dict(width=50, l
 
 
 def make(variant, cfg, E):
+    variant, _, opt = variant.partition(':')   # '<lib>:packed' = usage log with n packed entries per step (DMFB_VEC_LOG_STRIDE knob)
+    os.environ.pop('DMFB_VEC_LOG_STRIDE', None)
+    if opt == 'packed':
+        os.environ['DMFB_VEC_LOG_STRIDE'] = '0'
     name = 'dmfb_vec' if variant == 'main' else 'dmfb_vec_' + variant
     _lib._CACHE['dmfb_vec'] = C.CDLL(os.path.join(ROOT, 'marl_dmfb_amd', 'lib', 'lib%s.so' % name))
     return VecDMFB(n_envs=E, seed=3, **cfg)
