@@ -366,3 +366,12 @@ def test_observe_persistent_multi_tile_and_masks(cfg, E):
         want = want_full.copy()
         want[mask == 0] = 77
         assert np.array_equal(buf.cpu().numpy(), want), 'masked observe differs at frac %.2f' % frac
+
+
+def test_lockstep_maximum_sizes():
+    """The limits of include/dmfb_vec.h: 255 x 255 cells (positions packed in bytes, direction zoom over +-254, max_step
+    1020 = the usage-log length field nearly full), 16 droplets, maps on the global-atomic fold path; and a 1-droplet chip."""
+    _lockstep(dict(width=255, length=255, n_agents=16, fov=9, b_degrade=True, per_degrade=0.9), E=5, steps=40, seed=51,
+              autoreset=True, greedy=0.9)
+    _lockstep(dict(width=255, length=17, n_agents=16, fov=13, with_maps=True), E=3, steps=600, seed=52, autoreset=True, greedy=0.95)
+    _lockstep(dict(width=5, length=5, n_agents=1, fov=5), E=130, steps=40, seed=53, autoreset=True)

@@ -189,3 +189,12 @@ def test_observe_persistent_multi_tile_and_masks(version):
         want = O.observe()
         want[mask == 0] = 77
         assert np.array_equal(got, want), 'masked observe differs at frac %.2f' % frac
+
+
+def test_lockstep_maximum_sizes():
+    """The limits of include/meda_vec.h: 128 x 128 cells, 16 droplets (both observation versions), and the smallest legal
+    chip with one droplet."""
+    _lockstep(dict(width=128, length=128, n_agents=16, fov=19), E=6, steps=120, seed=41, autoreset=True, greedy=0.9)
+    _lockstep(dict(width=128, length=120, n_agents=16, fov=19, version=2, b_degrade=True, per_degrade=0.7), E=4, steps=100, seed=42,
+              autoreset=True, greedy=0.9)
+    _lockstep(dict(width=15, length=15, n_agents=1, fov=19, version=2), E=70, steps=40, seed=43, autoreset=True)
