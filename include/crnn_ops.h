@@ -34,20 +34,27 @@ int crnn_conv9_forward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, co
  *   d_out[r][0 .. od*25)            conv features
  *   d_out[r][od*25 .. od*25+10)     relu(mlp1(vec)),  vec = [obs[r][243], obs[r][244], onehot[r][0..n_actions)]
  * d_onehot: int8 [rows][n_actions] (may be NULL = all zeros: first step of an episode);
- * d_mlp_w: float32 [10][2+n_actions] (mlp1.weight), d_mlp_b: [10]; n_actions <= 16. */
+ * d_mlp_w: float32 [10][2+n_actions] (mlp1.weight), d_mlp_b: [10]; n_actions <= 16.
+ * out_cols: 0, or od*25+10 <= out_cols <= crnn_front_padded_cols(od) (and <= out_stride): the columns od*25+10 ..
+ * out_cols-1 of every row are written as ZEROS, so that the row can feed the GRU input projection as a GEMM operand with
+ * K = 640 (od 24) / 832 (od 32) against a weight zero-padded alike -- same sums, and rocBLAS runs K = 640 15-25 % faster
+ * than K = 610 on gfx950 (tools/probe/gemm_align_probe.py). */
 int crnn_front9_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
                         const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
-                        const float *d_mlp_b, int od, float *d_out, int64_t out_stride, void *stream);
+                        const float *d_mlp_b, int od, float *d_out, int64_t out_stride, int out_cols, void *stream);
+/* od*25+10 rounded up to a multiple of 64 (640 / 832), or CRNN_ERR_UNSUPPORTED. */
+int crnn_front_padded_cols(int od);
 /* The same front end for fov 19 (the MEDA v0_2 observation): conv_str(19) of network/base_net.py:23-33 =
  * Conv2d(3, od, 3, stride 2) + ReLU, then conv3 = Conv2d(od, od, 3) + ReLU applied TWICE (the two list entries are the
  * same module: tied weights), 19x19 -> 9x9 -> 7x7 -> 5x5, plus the vector branch as in crnn_front9_forward.
  * d_obs: int8 [rows][obs_stride >= 1085]: 3*19*19 pixel bytes (index c*361 + a*19 + b, the layout the MEDA observation
  *        kernel writes), then dir_x, dir_y;  d_w1 float32 [od][3][3][3], d_w3 float32 [od][od][3][3], biases [od];
  * d_out[r][0 .. od*25) conv features (index c*25 + h*5 + w), d_out[r][od*25 .. od*25+10) relu(mlp1(vec)).
- * d_mlp_w == NULL: pixel features only (obs_stride >= 1083, out_stride >= od*25).  od 24 or 32, n_actions <= 16. */
+ * d_mlp_w == NULL: pixel features only (obs_stride >= 1083, out_stride >= od*25).  od 24 or 32, n_actions <= 16.
+ * out_cols as in crnn_front9_forward. */
 int crnn_front19_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
                          const float *d_w1, const float *d_b1, const float *d_w3, const float *d_b3, const float *d_mlp_w,
-                         const float *d_mlp_b, int od, float *d_out, int64_t out_stride, void *stream);
+                         const float *d_mlp_b, int od, float *d_out, int64_t out_stride, int out_cols, void *stream);
 /* Gradients of the four conv tensors for the eval network of VDN.learn (policy/vdn.py:123-128 backward through
  * network/base_net.py:63-65); the observation needs none.  Nothing is saved by the forward: the conv1 activations of each
  * row block are recomputed inside the kernel (f32 MFMA, as the forward computes them) and the next block's inputs are

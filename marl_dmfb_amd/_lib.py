@@ -148,8 +148,9 @@ def crnn_ops():
         return lib
     vp, i64 = C.c_void_p, C.c_int64
     lib.crnn_conv9_forward.argtypes = [vp, i64, i64, vp, vp, vp, vp, C.c_int, vp, i64, vp]
-    lib.crnn_front9_forward.argtypes = [vp, i64, vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, i64, vp]
-    lib.crnn_front19_forward.argtypes = [vp, i64, vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, i64, vp]
+    lib.crnn_front9_forward.argtypes = [vp, i64, vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, i64, C.c_int, vp]
+    lib.crnn_front19_forward.argtypes = [vp, i64, vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, i64, C.c_int, vp]
+    lib.crnn_front_padded_cols.argtypes = [C.c_int]
     lib.crnn_conv9_backward_parts.argtypes = [C.c_int]
     lib.crnn_conv9_backward.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
     lib.crnn_last_hip_error.argtypes = []

@@ -131,11 +131,13 @@ class Evaluator:
         fused_tail = (self.fuse_tail and hasattr(net, 'act_ok') and net.act_ok(obs.reshape(E * n, -1)) and hidden.is_contiguous()
                       and hidden.dtype == torch.float32 and hidden.shape[1] == 128 and net.fc1.weight.is_contiguous())
         t_played = 0
+        # the GRU input projection runs against rnn.weight_ih zero-padded to K = 640 / 832: one in-place copy per episode
+        w_ih_pad = net.refresh_padded() if fused_tail else None
         for t in range(T):
             obs2, la2 = obs.reshape(E * n, -1), last_action.reshape(E * n, -1)
             if fused_tail:
                 # front end + the two GRU GEMMs, then gate math + fc1 + epsilon-greedy in one launch (h updated in place)
-                ig, hg = net.act_gates(obs2, la2, hidden)
+                ig, hg = net.act_gates(obs2, la2, hidden, w_ih_pad)
                 rc = lib.rollout_gru_head_select(vp(ig.data_ptr()), vp(hg.data_ptr()), vp(net.rnn.bias_ih.data_ptr()),
                                                  vp(net.rnn.bias_hh.data_ptr()), vp(hidden.data_ptr()), vp(net.fc1.weight.data_ptr()),
                                                  vp(net.fc1.bias.data_ptr()), E, n, hidden.shape[1], A, vp(eps.data_ptr()),

@@ -28,7 +28,8 @@ template <int OD> struct Geo {
                                                          // spreads the epilogue's 16 channel lanes over 16 different banks
     static constexpr int CS2 = 53;                       // stage-2 activation stride per channel (49 used), as crnn_mfma.h
     static constexpr int ROW_A1 = OD * CS1, ROW_A2 = OD * CS2;
-    static constexpr int OUT_STRIDE = OD * 25 + 12;      // staged output row: conv features | 10 vector features | pad
+    static constexpr int PAD_COLS = (OD * 25 + 10 + 63) / 64 * 64;  // a row may be written out zero-padded (see crnn_mfma.h)
+    static constexpr int OUT_STRIDE = PAD_COLS + 4;      // staged output row: conv features | 10 vector features | zeros
     static constexpr int KQ = OD / 4;                    // channel quads
     static constexpr int NSTEP = KQ * 9;                 // conv3 k-steps
     static constexpr int M2 = RB * 49, M3 = RB * 25;
@@ -118,7 +119,7 @@ template <int OD>
 __global__ __launch_bounds__(kBlockM) void k_conv19_mfma(const int8_t *__restrict__ obs, long obs_stride, long rows,
                                                          const float *__restrict__ w1, const float *__restrict__ b1,
                                                          const float *__restrict__ w3, const float *__restrict__ b3,
-                                                         float *__restrict__ out, long out_stride,
+                                                         float *__restrict__ out, long out_stride, int out_cols,
                                                          const int8_t *__restrict__ onehot, int n_actions,
                                                          const float *__restrict__ mlp_w, const float *__restrict__ mlp_b) {
     using G = Geo<OD>;
@@ -157,7 +158,8 @@ __global__ __launch_bounds__(kBlockM) void k_conv19_mfma(const int8_t *__restric
         for (int tap = 0; tap < 9; ++tap) bw3[cq * 9 + tap] = chv ? w3[((size_t)ch * OD + 4 * cq + kq) * 9 + tap] : 0.0f;
     const float bias1 = chv ? b1[ch] : 0.0f, bias3 = chv ? b3[ch] : 0.0f;
     const int n_feat = OD * 25 + (mlp_w ? 10 : 0);
-    const bool wide_out = (out_stride % 2 == 0) && (((size_t)out) % 8 == 0);
+    const int n_out = out_cols > n_feat ? out_cols : n_feat;  // columns n_feat .. n_out-1 of a row are written as zeros
+    const bool wide_out = (out_stride % 2 == 0) && (((size_t)out) % 8 == 0) && (n_out % 2 == 0);
 
     const long n_blocks = (rows + G::RB - 1) / G::RB;
     const int nin = 2 + n_actions;
@@ -240,19 +242,24 @@ __global__ __launch_bounds__(kBlockM) void k_conv19_mfma(const int8_t *__restric
             if (t < G::T3) conv3_tiles<OD, 1, 7, 5, G::CS2, G::ROW_A2, G::M3>(s_a2, s_out, G::OUT_STRIDE, 25, bw3, bias3, t, t, j, kq, ch, chv);
         }
         if (mlp_w && tid < G::RB * 10) s_out[mr * G::OUT_STRIDE + OD * 25 + mc] = fmaxf(mv, 0.0f);
+        if (n_out > n_feat)  // the zero tail of the staged rows (their LDS held stage-1 activations until stage 2 was done)
+            for (int i = tid; i < G::RB * (n_out - n_feat); i += kBlockM) {
+                const int rr = i / (n_out - n_feat), k = i - rr * (n_out - n_feat);
+                s_out[rr * G::OUT_STRIDE + n_feat + k] = 0.0f;
+            }
         __syncthreads();
         // ---- stream the staged rows out: a wave per row, consecutive lanes on consecutive floats
-        if (wide_out) {  // 8-byte stores: n_feat, OUT_STRIDE and (checked once) out / out_stride are even
+        if (wide_out) {  // 8-byte stores: n_out, OUT_STRIDE and (checked once) out / out_stride are even
             for (int rr = wave; rr < rv; rr += kBlockM / 64) {
                 float2 *dst = (float2 *)(out + (row0 + rr) * out_stride);
                 const float2 *src = (const float2 *)(s_out + rr * G::OUT_STRIDE);
-                for (int k = lane; k < n_feat / 2; k += 64) dst[k] = src[k];
+                for (int k = lane; k < n_out / 2; k += 64) dst[k] = src[k];
             }
         } else {
             for (int rr = wave; rr < rv; rr += kBlockM / 64) {
                 float *dst = out + (row0 + rr) * out_stride;
                 const float *src = s_out + rr * G::OUT_STRIDE;
-                for (int k = lane; k < n_feat; k += 64) dst[k] = src[k];
+                for (int k = lane; k < n_out; k += 64) dst[k] = src[k];
             }
         }
         // next iteration: s_a1 (= s_out) is rewritten after its first barrier

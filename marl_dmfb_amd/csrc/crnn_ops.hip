@@ -393,7 +393,7 @@ struct PerDeviceOnce {
 
 template <int OD>
 int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w2, const float *b2,
-           float *out, long out_stride, const int8_t *onehot, int n_actions, const float *mlp_w, const float *mlp_b, hipStream_t s) {
+           float *out, long out_stride, int out_cols, const int8_t *onehot, int n_actions, const float *mlp_w, const float *mlp_b, hipStream_t s) {
     using GM = crnn_mfma::GeoM<OD>;
     const size_t lds = GM::LDS_FLOATS * sizeof(float);
     static PerDeviceOnce attr_set;
@@ -406,7 +406,7 @@ int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const
     const int grid = (int)(n_blocks < 256 ? n_blocks : 256);  // persistent: one workgroup per CU keeps the weights resident
     (void)hipGetLastError();
     hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, s, obs, obs_stride, rows, w1, b1, w2, b2,
-                       out, out_stride, onehot, n_actions, mlp_w, mlp_b);
+                       out, out_stride, out_cols, onehot, n_actions, mlp_w, mlp_b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
     return CRNN_OK;
@@ -414,7 +414,7 @@ int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const
 
 template <int OD>
 int launch19(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w3, const float *b3,
-             float *out, long out_stride, const int8_t *onehot, int n_actions, const float *mlp_w, const float *mlp_b, hipStream_t s) {
+             float *out, long out_stride, int out_cols, const int8_t *onehot, int n_actions, const float *mlp_w, const float *mlp_b, hipStream_t s) {
     using GM = crnn_mfma19::Geo<OD>;
     const size_t lds = GM::LDS_FLOATS * sizeof(float);
     static PerDeviceOnce attr_set;
@@ -427,7 +427,7 @@ int launch19(const int8_t *obs, long obs_stride, long rows, const float *w1, con
     const int grid = (int)(n_blocks < 256 ? n_blocks : 256);  // persistent: one workgroup per CU keeps the weights in registers
     (void)hipGetLastError();
     hipLaunchKernelGGL((crnn_mfma19::k_conv19_mfma<OD>), dim3(grid), dim3(crnn_mfma19::kBlockM), lds, s, obs, obs_stride, rows, w1, b1, w3,
-                       b3, out, out_stride, onehot, n_actions, mlp_w, mlp_b);
+                       b3, out, out_stride, out_cols, onehot, n_actions, mlp_w, mlp_b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
     return CRNN_OK;
@@ -464,34 +464,39 @@ int crnn_conv9_forward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, co
     if (!d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_out || rows < 0 || obs_stride < 243 || out_stride < od * 25)
         return CRNN_ERR_BAD_ARG;
     if (rows == 0) return CRNN_OK;
-    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
-    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, 0, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, 0, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
 }
 
 int crnn_front9_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
                         const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
-                        const float *d_mlp_b, int od, float *d_out, int64_t out_stride, void *stream) {
+                        const float *d_mlp_b, int od, float *d_out, int64_t out_stride, int out_cols, void *stream) {
     if (!d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_mlp_w || !d_mlp_b || !d_out || rows < 0 || obs_stride < 245 ||
         out_stride < od * 25 + 10 || n_actions < 0 || n_actions > 16)
         return CRNN_ERR_BAD_ARG;
+    if (od != 24 && od != 32) return CRNN_ERR_UNSUPPORTED;
+    if (out_cols != 0 && (out_cols < od * 25 + 10 || out_cols > crnn_front_padded_cols(od) || out_cols > out_stride)) return CRNN_ERR_BAD_ARG;
     if (rows == 0) return CRNN_OK;
-    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
-    if (od == 32) return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
-    return CRNN_ERR_UNSUPPORTED;
+    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, out_cols, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
+    return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, out_cols, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
 }
+
+int crnn_front_padded_cols(int od) { return od == 24 ? crnn_mfma::GeoM<24>::PAD_COLS : od == 32 ? crnn_mfma::GeoM<32>::PAD_COLS : CRNN_ERR_UNSUPPORTED; }
 
 int crnn_front19_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
                          const float *d_w1, const float *d_b1, const float *d_w3, const float *d_b3, const float *d_mlp_w,
-                         const float *d_mlp_b, int od, float *d_out, int64_t out_stride, void *stream) {
+                         const float *d_mlp_b, int od, float *d_out, int64_t out_stride, int out_cols, void *stream) {
     const bool vec = d_mlp_w != nullptr;
+    const int n_feat = od * 25 + (vec ? 10 : 0);
     if (!d_obs || !d_w1 || !d_b1 || !d_w3 || !d_b3 || !d_out || rows < 0 || obs_stride < 3 * 19 * 19 + (vec ? 2 : 0) ||
-        out_stride < od * 25 + (vec ? 10 : 0) || n_actions < 0 || n_actions > 16 || (vec && !d_mlp_b))
+        out_stride < n_feat || n_actions < 0 || n_actions > 16 || (vec && !d_mlp_b))
         return CRNN_ERR_BAD_ARG;
+    if (od != 24 && od != 32) return CRNN_ERR_UNSUPPORTED;
+    if (out_cols != 0 && (out_cols < n_feat || out_cols > crnn_front_padded_cols(od) || out_cols > out_stride)) return CRNN_ERR_BAD_ARG;
     if (rows == 0) return CRNN_OK;
-    if (od == 24) return launch19<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w3, d_b3, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
-    if (od == 32) return launch19<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w3, d_b3, d_out, out_stride, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
-    return CRNN_ERR_UNSUPPORTED;
+    if (od == 24) return launch19<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w3, d_b3, d_out, out_stride, out_cols, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
+    return launch19<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w3, d_b3, d_out, out_stride, out_cols, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
 }
 
 int crnn_conv9_backward_parts(int od) { return od == 24 ? GeoB<24>::PART : od == 32 ? GeoB<32>::PART : CRNN_ERR_UNSUPPORTED; }

@@ -106,18 +106,18 @@ class _Front9Train(torch.autograd.Function):
     the row-strided gradient in place, recomputing conv1) and two small split-K GEMMs for mlp1."""
 
     @staticmethod
-    def forward(ctx, obs_i8, onehot_i8, w1, b1, w2, b2, mlp_w, mlp_b):
+    def forward(ctx, obs_i8, onehot_i8, w1, b1, w2, b2, mlp_w, mlp_b, cols):
         import ctypes as C
         from .. import _lib
         lib = _lib.crnn_ops()
         vp = C.c_void_p
         obs_i8, onehot_i8 = obs_i8.contiguous(), onehot_i8.contiguous()
         R, od, A = obs_i8.shape[0], w1.shape[0], onehot_i8.shape[1]
-        x = torch.empty((R, od * 25 + 10), dtype=torch.float32, device=obs_i8.device)
+        x = torch.empty((R, cols), dtype=torch.float32, device=obs_i8.device)  # cols > od*25+10: zero tail (GEMM-friendly K)
         w1c, b1c, w2c, b2c, mwc, mbc = (t.detach().contiguous() for t in (w1, b1, w2, b2, mlp_w, mlp_b))
         rc = lib.crnn_front9_forward(vp(obs_i8.data_ptr()), obs_i8.stride(0), vp(onehot_i8.data_ptr()), A, R, vp(w1c.data_ptr()),
                                      vp(b1c.data_ptr()), vp(w2c.data_ptr()), vp(b2c.data_ptr()), vp(mwc.data_ptr()),
-                                     vp(mbc.data_ptr()), od, vp(x.data_ptr()), x.stride(0),
+                                     vp(mbc.data_ptr()), od, vp(x.data_ptr()), x.stride(0), cols,
                                      vp(torch.cuda.current_stream(obs_i8.device).cuda_stream))
         if rc != 0:
             raise RuntimeError('crnn_front9_forward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
@@ -132,11 +132,11 @@ class _Front9Train(torch.autograd.Function):
         od = s1[0]
         n2 = od * od * 9
         tot = _conv9_backward(obs_i8, x, g, w1c, b1c, w2c, od)
-        gz = g[:, od * 25:] * (x[:, od * 25:] > 0)
+        gz = g[:, od * 25:od * 25 + 10] * (x[:, od * 25:od * 25 + 10] > 0)
         vec = torch.cat([obs_i8[:, 243:245].float(), onehot_i8.float()], dim=1)
         g_mw = _wgrad_splitk(gz.contiguous(), vec)
         return (None, None, tot[n2 + od:n2 + od + od * 27].view(s1), tot[n2 + od + od * 27:], tot[:n2].view(s2), tot[n2:n2 + od],
-                g_mw, gz.sum(0))
+                g_mw, gz.sum(0), None)
 
 
 class _LinearSplitK(torch.autograd.Function):
@@ -357,7 +357,9 @@ class CRNN(nn.Module):
         h = h0.reshape(-1, self.rnn_hidden_dim)
         hs = []
         if x_seq.is_cuda:
-            igates = _LinearSplitK.apply(x_seq.reshape(T * R, -1), self.rnn.weight_ih, None).view(T, R, -1)
+            # rows from the HIP front end come zero-padded to `padded_cols()` (K = 640 / 832 for the GEMM)
+            w_ih = self.weight_ih_padded() if x_seq.shape[-1] == self.padded_cols() != self.rnn.weight_ih.shape[1] else self.rnn.weight_ih
+            igates = _LinearSplitK.apply(x_seq.reshape(T * R, -1), w_ih, None).view(T, R, -1)
             hseq = gru_sequence(igates, h, self.rnn.weight_hh, self.rnn.bias_ih, self.rnn.bias_hh,
                                 getattr(self, 'gru_impl', 'hip'))
             q = _LinearSplitK.apply(hseq.view(T * R, -1), self.fc1.weight, self.fc1.bias).view(T, R, -1)
@@ -388,7 +390,7 @@ class CRNN(nn.Module):
             rc = lib.crnn_front19_forward(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), None, 0, R,
                                           C.c_void_p(c1.weight.data_ptr()), C.c_void_p(c1.bias.data_ptr()),
                                           C.c_void_p(c2.weight.data_ptr()), C.c_void_p(c2.bias.data_ptr()), None, None,
-                                          c1.out_channels, C.c_void_p(out.data_ptr()), out.stride(0), stream)
+                                          c1.out_channels, C.c_void_p(out.data_ptr()), out.stride(0), 0, stream)
         else:
             rc = lib.crnn_conv9_forward(C.c_void_p(obs_i8.data_ptr()), obs_i8.stride(0), R,
                                         C.c_void_p(c1.weight.data_ptr()), C.c_void_p(c1.bias.data_ptr()),
@@ -398,15 +400,38 @@ class CRNN(nn.Module):
             raise RuntimeError('crnn_conv9_forward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
         return out
 
-    def _front_features_hip(self, obs_i8, onehot_i8):
+    def padded_cols(self):
+        """GRU input width rounded up to a multiple of 64 (include/crnn_ops.h: crnn_front_padded_cols)."""
+        return (self.out + 10 + 63) // 64 * 64
+
+    def weight_ih_padded(self):
+        """rnn.weight_ih with zero columns up to `padded_cols()` (a fresh tensor; inside the autograd graph when
+        gradients are on: the pad's gradient is sliced away)."""
+        w = self.rnn.weight_ih
+        return f.pad(w, (0, self.padded_cols() - w.shape[1]))
+
+    def refresh_padded(self):
+        """The same, copied IN PLACE into a persistent buffer: the rollout calls this once per episode (weights do not
+        change inside one) and hands the buffer to `act_gates`; a captured rollout graph re-runs the copy on every
+        replay.  No version check on purpose: the fused Adam step does not bump a parameter's `_version`."""
+        w = self.rnn.weight_ih.detach()
+        buf = getattr(self, '_w_ih_pad', None)
+        if buf is None or buf.device != w.device or buf.shape != (w.shape[0], self.padded_cols()):
+            buf = self._w_ih_pad = w.new_zeros((w.shape[0], self.padded_cols()))
+        buf[:, :w.shape[1]].copy_(w)
+        return buf
+
+    def _front_features_hip(self, obs_i8, onehot_i8, padded=False):
         """GRU input x = cat([conv features, relu(mlp1([dir, last action]))]) in one HIP launch
-        (include/crnn_ops.h: crnn_front9_forward); inference only."""
+        (include/crnn_ops.h: crnn_front9_forward / crnn_front19_forward); inference only.  padded: rows of `padded_cols()`
+        floats with a zero tail, for the GEMM against `weight_ih_padded()`."""
         import ctypes as C
         from .. import _lib
         lib = _lib.crnn_ops()
         obs_i8 = obs_i8.contiguous()
         R = obs_i8.shape[0]
-        out = torch.empty((R, self.out + 10), dtype=torch.float32, device=obs_i8.device)
+        cols = self.padded_cols() if padded else self.out + 10
+        out = torch.empty((R, cols), dtype=torch.float32, device=obs_i8.device)
         c1, c2 = self.convs[0], self.convs[1]
         oh = None
         if onehot_i8 is not None:
@@ -418,7 +443,7 @@ class CRNN(nn.Module):
                                      C.c_void_p(c1.weight.data_ptr()), C.c_void_p(c1.bias.data_ptr()),
                                      C.c_void_p(c2.weight.data_ptr()), C.c_void_p(c2.bias.data_ptr()),
                                      C.c_void_p(self.mlp1.weight.data_ptr()), C.c_void_p(self.mlp1.bias.data_ptr()),
-                                     c1.out_channels, C.c_void_p(out.data_ptr()), out.stride(0),
+                                     c1.out_channels, C.c_void_p(out.data_ptr()), out.stride(0), cols,
                                      C.c_void_p(torch.cuda.current_stream(obs_i8.device).cuda_stream))
         if rc != 0:
             raise RuntimeError('crnn_front%d_forward failed: %d (hip %d)' % (self._hip_geometry(), rc, lib.crnn_last_hip_error()))
@@ -430,7 +455,7 @@ class CRNN(nn.Module):
         c1, c2 = self.convs[0], self.convs[1]
         if self.mlp1.in_features == 2 + self.n_actions and self.n_actions <= 16 and self.mlp1.out_features == 10:
             return _Front9Train.apply(obs_i8, la_rows.to(torch.int8), c1.weight, c1.bias, c2.weight, c2.bias,
-                                      self.mlp1.weight, self.mlp1.bias)
+                                      self.mlp1.weight, self.mlp1.bias, self.padded_cols())
         pix = _ConvFront9.apply(obs_i8, c1.weight, c1.bias, c2.weight, c2.bias)
         vec = torch.cat([obs_i8[:, self.n_pixel:].float(), la_rows.float()], dim=1)
         return torch.cat([pix, f.relu(self.mlp1(vec))], dim=1)
@@ -460,11 +485,12 @@ class CRNN(nn.Module):
         return (self._hip_conv_ok(obs_i8) and self.mlp1.in_features == 2 + self.n_actions and self.n_actions <= 16
                 and self.mlp1.out_features == 10)
 
-    def act_gates(self, obs_i8, last_action_onehot, hidden_state):
+    def act_gates(self, obs_i8, last_action_onehot, hidden_state, w_ih_padded=None):
         """The GEMM part of one rollout lock-step: x = front end (HIP), then the two GRU projections x W_ih^T and
         h W_hh^T (no bias).  The gate math, fc1 and the epsilon-greedy pick follow in ONE kernel."""
-        x = self._front_features_hip(obs_i8, last_action_onehot)
-        return torch.matmul(x, self.rnn.weight_ih.t()), torch.matmul(hidden_state, self.rnn.weight_hh.t())
+        x = self._front_features_hip(obs_i8, last_action_onehot, padded=True)
+        w = self.weight_ih_padded() if w_ih_padded is None else w_ih_padded  # `refresh_padded()` of this episode
+        return torch.matmul(x, w.t()), torch.matmul(hidden_state, self.rnn.weight_hh.t())
 
     def forward_obs(self, obs_i8, last_action_onehot, hidden_state):
         """obs_i8 (R, 3*fov*fov+2) int8 as written by the env kernels; last_action_onehot (R, n_actions)."""

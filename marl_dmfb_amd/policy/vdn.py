@@ -213,7 +213,7 @@ class VDN:
     def _features(self, net, obs_rows, la_rows):
         if la_rows is not None and hasattr(net, '_hip_conv_ok') and net._hip_conv_ok(obs_rows):
             # no-grad pass (target net) over int8 rows: hand-written HIP conv front end
-            return net._front_features_hip(obs_rows, la_rows)
+            return net._front_features_hip(obs_rows, la_rows, padded=hasattr(net, 'recurrent_seq'))
         if la_rows is not None and hasattr(net, '_hip_train_ok') and net._hip_train_ok(obs_rows):
             return net.features_obs_train(obs_rows, la_rows)  # eval net: HIP conv forward + backward
         x = obs_rows.float()

@@ -84,7 +84,7 @@ def test_crnn_ops_library_exports():
     txt = open(os.path.join(ROOT, 'include', 'crnn_ops.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     names = sorted(set(re.findall(r'\b(crnn_[a-z_0-9]+)\s*\(', txt)))
-    assert names == ['crnn_conv9_backward', 'crnn_conv9_backward_parts', 'crnn_conv9_forward', 'crnn_front19_forward', 'crnn_front9_forward', 'crnn_last_hip_error']
+    assert names == ['crnn_conv9_backward', 'crnn_conv9_backward_parts', 'crnn_conv9_forward', 'crnn_front19_forward', 'crnn_front9_forward', 'crnn_front_padded_cols', 'crnn_last_hip_error']
     gru = sorted(set(re.findall(r'\b(gru_[a-z_0-9]+)\s*\(', txt)))
     assert gru == ['gru_last_hip_error', 'gru_seq_backward', 'gru_seq_forward', 'gru_seq_row_blocks']
     for n in names + gru:
@@ -92,7 +92,8 @@ def test_crnn_ops_library_exports():
     # argument guards run on the host before anything touches the GPU
     assert lib.crnn_conv9_forward(None, 245, 4, None, None, None, None, 24, None, 600, None) == -1
     assert lib.gru_seq_forward(None, None, None, None, None, 4, 8, 128, None, None, None) == -1
-    assert lib.crnn_front19_forward(None, 1085, None, 9, 4, None, None, None, None, None, None, 32, None, 810, None) == -1
+    assert lib.crnn_front19_forward(None, 1085, None, 9, 4, None, None, None, None, None, None, 32, None, 810, 0, None) == -1
+    assert lib.crnn_front_padded_cols(24) == 640 and lib.crnn_front_padded_cols(32) == 832 and lib.crnn_front_padded_cols(16) < 0
 
 
 def test_rollout_ops_library_exports():

@@ -222,12 +222,18 @@ def test_front9_train_node_matches_torch_autograd(od, rows):
     net = CRNN(a).cuda()
     obs = torch.randint(-3, 8, (rows, 245), dtype=torch.int8, device='cuda')
     oh = torch.nn.functional.one_hot(torch.randint(0, 5, (rows,), device='cuda'), 5).to(torch.int8)
-    gout = torch.randn(rows, od * 25 + 10, device='cuda')
+    # odd row counts use the zero-padded row width (the GEMM-friendly K of the GRU input projection), even ones the exact one
+    nf = od * 25 + 10
+    cols = net.padded_cols() if rows % 2 else nf
+    gfull = torch.randn(rows, cols, device='cuda')      # the gradient of the zero tail is arbitrary and must be ignored
     safe = _safe_rows(net, obs)
-    gout = gout * safe[:, None]
+    gfull[:, :nf] *= safe[:, None]
+    gout = gfull[:, :nf]
     c1, c2 = net.convs
-    x = _Front9Train.apply(obs, oh, c1.weight, c1.bias, c2.weight, c2.bias, net.mlp1.weight, net.mlp1.bias)
-    (x * gout).sum().backward()
+    xfull = _Front9Train.apply(obs, oh, c1.weight, c1.bias, c2.weight, c2.bias, net.mlp1.weight, net.mlp1.bias, cols)
+    assert xfull.shape == (rows, cols) and bool((xfull[:, nf:] == 0).all())
+    (xfull * gfull).sum().backward()
+    x = xfull[:, :nf]
     params = (c1.weight, c1.bias, c2.weight, c2.bias, net.mlp1.weight, net.mlp1.bias)
     got = [p.grad.detach().cpu().clone() for p in params]
     ref = CRNN(a).double()
@@ -242,3 +248,32 @@ def test_front9_train_node_matches_torch_autograd(od, rows):
         err = _rel_l2(g.numpy(), r.numpy())
         print('front9 od=%d rows=%d %s rel_l2=%.2e' % (od, rows, name, err))
         assert err <= GRAD_TOL, (name, err)
+
+
+@pytest.mark.parametrize('fov,od,rows', [(9, 24, 4097), (9, 32, 33), (19, 32, 1000), (19, 24, 5)])
+def test_front_end_zero_padded_rows(fov, od, rows):
+    """out_cols > od*25+10: the same features followed by zeros up to a multiple of 64 (crnn_front_padded_cols), for both
+    front-end kernels; the GRU input projection against the zero-padded weight_ih equals the unpadded one up to the
+    GEMM's summation order, also after the weights changed in place (cached padded copy refreshed)."""
+    from marl_dmfb_amd.network.base_net import CRNN
+    nA = 9 if fov == 19 else 5
+    obs_len = 3 * fov * fov + 2
+    a = types.SimpleNamespace(obs_shape=(3, fov, fov, 2, obs_len), hyper_hidden_dim=od, rnn_hidden_dim=128, n_actions=nA, fov=fov)
+    torch.manual_seed(fov * od + rows)
+    net = CRNN(a).cuda()
+    obs = torch.randint(0, 6, (rows, obs_len), dtype=torch.int8, device='cuda')
+    la = torch.nn.functional.one_hot(torch.randint(0, nA, (rows,), device='cuda'), nA).to(torch.int8)
+    h = torch.randn(rows, 128, device='cuda')
+    nf = od * 25 + 10
+    with torch.no_grad():
+        x = net._front_features_hip(obs, la)
+        xp = net._front_features_hip(obs, la, padded=True)
+        assert xp.shape == (rows, (nf + 63) // 64 * 64) == (rows, net.padded_cols())
+        assert torch.equal(xp[:, :nf], x) and bool((xp[:, nf:] == 0).all())
+        opt = torch.optim.Adam([net.rnn.weight_ih], lr=0.05, fused=True)   # its step does not bump the parameter's _version
+        for it in range(3):
+            ig, hg = net.act_gates(obs, la, h, net.refresh_padded() if it else None)
+            ref = torch.matmul(x.double(), net.rnn.weight_ih.double().t())
+            np.testing.assert_allclose(ig.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=2e-5)
+            net.rnn.weight_ih.grad = torch.randn_like(net.rnn.weight_ih)
+            opt.step()
