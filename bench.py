@@ -67,7 +67,8 @@ def parse(argv=None):
     ap.add_argument('--batch_size', type=int, default=512, help='episodes per learn')
     ap.add_argument('--train_time', type=int, default=4, help='learns per round')
     ap.add_argument('--buffer_size', type=int, default=16384, help='episodes kept in the HBM replay buffer')
-    ap.add_argument('--graph', action='store_true', help='replay the rollout as a captured HIP graph')
+    ap.add_argument('--no_graph', dest='graph', action='store_false',
+                    help='play the rollout eagerly instead of replaying it as a captured HIP graph (the default)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_tiers', action='store_true')
     ap.add_argument('--cpu_seconds', type=float, default=20.0, help='wall seconds of the cpu_baseline sample')

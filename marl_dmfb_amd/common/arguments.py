@@ -47,6 +47,8 @@ def common_parser():
     p.add_argument('--version', '-v', type=str, default=None)
     # vectorised-loop additions
     p.add_argument('--n_envs', type=int, default=4096, help='chips advanced in lock-step per GPU')
+    p.add_argument('--no_graph', dest='use_graph', default=None, action='store_false',
+                   help='play the rollout eagerly instead of replaying it as a captured HIP graph')
     p.add_argument('--dist', default=False, action='store_true', help='shard chips over ranks, all-reduce gradients')
     return p
 

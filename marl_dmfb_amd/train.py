@@ -28,7 +28,10 @@ class Trainer:
         self.args = args
         self.agents = Agents(args)
         self.rolloutWorker = RolloutWorker(env, self.agents, args)
-        self.rolloutWorker.use_graph = bool(getattr(args, 'use_graph', False))
+        # the lock-step episode is replayed as ONE captured HIP graph by default on the GPU (bit-identical to the eager
+        # rollout: tests/test_gpu_rollout_graph.py); --no_graph / use_graph=False plays it eagerly
+        use_graph = getattr(args, 'use_graph', None)
+        self.rolloutWorker.use_graph = (torch.device(env.device).type == 'cuda') if use_graph is None else bool(use_graph)
         self.buffer = ReplayBuffer(args, device=env.device)
         self.episode_rewards, self.episode_steps = [], []
         self.episode_constraints, self.success_rate, self.time_cost = [], [], []

@@ -1,0 +1,68 @@
+"""The rollout replayed as a captured HIP graph (RolloutWorker.use_graph) against the eager rollout: same seeds, same
+chips -> identical episodes, statistics and epsilon schedule, over several collect+learn rounds (the graph must see the
+weights the learns in between produced, incl. the zero-padded copy of rnn.weight_ih), and for greedy evaluation."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(use_graph, name='dmfb'):
+    from marl_dmfb_amd.common.arguments import make_args
+    from marl_dmfb_amd.train import Trainer
+    if name == 'dmfb':
+        from marl_dmfb_amd.env.dmfb import VecDMFB
+        env = VecDMFB(10, 10, 4, fov=9, n_envs=256, seed=11, device='cuda:0')
+        kw = {}
+    else:
+        from marl_dmfb_amd.env.meda import VecMEDA
+        env = VecMEDA(30, 30, 4, fov=19, n_envs=64, seed=11, device='cuda:0', version=2)
+        kw = dict(name='meda', drop_num=4, width=30, length=30, fov=19)
+    torch.manual_seed(5)
+    args = make_args(device='cuda:0', n_envs=env.n_envs, batch_size=64, train_time=2, buffer_size=4 * env.n_envs, anneal_steps=20000,
+                     use_graph=use_graph, **kw, **env.get_env_info())
+    return Trainer(env, args)
+
+
+@pytest.mark.parametrize('name', ['dmfb', 'meda'])
+def test_graph_rollout_equals_eager_rollout(name):
+    a, b = _trainer(False, name), _trainer(True, name)
+    assert b.rolloutWorker.use_graph and not a.rolloutWorker.use_graph
+    b.agents.policy.eval_rnn.load_state_dict(a.agents.policy.eval_rnn.state_dict())
+    b.agents.policy.target_rnn.load_state_dict(a.agents.policy.target_rnn.state_dict())
+    # building a graph plays one warm-up episode outside the capture (lazy initialisations must not be captured): the chips
+    # and the device-side draw counter of the eager side are advanced by the same throw-away episode
+    a.agents.policy.init_hidden(1)
+    a.rolloutWorker._play(a.rolloutWorker.epsilon.clone(), False, True)
+    for rnd in range(3):
+        ra = a.rolloutWorker.generate_episode()
+        rb = b.rolloutWorker.generate_episode()
+        for k in range(4):
+            assert torch.equal(ra[k], rb[k]), ('stat', k, rnd)
+        for key in ra[4]:
+            assert torch.equal(ra[4][key], rb[4][key]), (key, rnd)
+        assert float(a.rolloutWorker.epsilon) == float(b.rolloutWorker.epsilon)
+        # the same learn on both sides: identical batches (same sampler seed), so the weights stay identical
+        for tr, ep in ((a, ra[4]), (b, rb[4])):
+            tr.buffer.store_episode(ep)
+        for tr in (a, b):
+            if tr.buffer.generator is not None:
+                tr.buffer.generator.manual_seed(100 + rnd)
+            else:
+                torch.manual_seed(100 + rnd)
+        batch = a.buffer.sample(64)
+        if b.buffer.generator is None:
+            torch.manual_seed(100 + rnd)
+        batch_b = b.buffer.sample(64)
+        for key in batch:
+            assert torch.equal(torch.as_tensor(batch[key]), torch.as_tensor(batch_b[key])), key
+        a.agents.train(batch, rnd)
+        b.agents.train(batch_b, rnd)
+        for (ka, pa), (kb, pb) in zip(a.agents.policy.eval_rnn.state_dict().items(), b.agents.policy.eval_rnn.state_dict().items()):
+            assert torch.equal(pa, pb), ('weights diverged', ka, rnd)
+    a.agents.policy.init_hidden(1)
+    a.rolloutWorker._play(0.0, True, False)    # the evaluation graph's warm-up episode
+    ea = a.rolloutWorker._generate_episode()   # greedy evaluation episode (its own graph)
+    eb = b.rolloutWorker._generate_episode()
+    for k in range(4):
+        assert torch.equal(ea[k], eb[k]), ('eval stat', k)
