@@ -199,15 +199,20 @@ class VDN:
         o = _t(batch['o'], dev, batch['o'].dtype if isinstance(batch['o'], torch.Tensor) else torch.float32)
         o_next = _t(batch['o_next'], dev, o.dtype)
         B = o.shape[0]
-        obs_seq = torch.cat([o[:, :1], o_next[:, :T]], dim=1)                       # (B, T+1, n, obs)
-        obs_seq = obs_seq.permute(1, 0, 2, 3).reshape(T + 1, B * self.n_agents, -1)
+        # written time-major directly (one transposing copy; no intermediate (B, T+1, ...) concatenation)
+        obs_seq = torch.empty((T + 1, B) + tuple(o.shape[2:]), dtype=o.dtype, device=dev)
+        obs_seq[0].copy_(o[:, 0])
+        obs_seq[1:].copy_(o_next[:, :T].permute(1, 0, 2, 3))
+        obs_seq = obs_seq.view(T + 1, B * self.n_agents, -1)
         la = None
         if self.args.last_action:
             src = batch['u_onehot']
             keep = isinstance(src, torch.Tensor) and src.dtype == torch.int8 and o.dtype == torch.int8
             uo = _t(src, dev, torch.int8 if keep else torch.float32)   # int8 stays int8 for the HIP front end
-            la = torch.cat([torch.zeros_like(uo[:, :1]), uo[:, :T]], dim=1)
-            la = la.permute(1, 0, 2, 3).reshape(T + 1, B * self.n_agents, -1)
+            la = torch.empty((T + 1, B) + tuple(uo.shape[2:]), dtype=uo.dtype, device=dev)
+            la[0].zero_()
+            la[1:].copy_(uo[:, :T].permute(1, 0, 2, 3))
+            la = la.view(T + 1, B * self.n_agents, -1)
         return obs_seq, la
 
     def _features(self, net, obs_rows, la_rows):
