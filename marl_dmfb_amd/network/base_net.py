@@ -41,7 +41,7 @@ class _ConvGemm(torch.autograd.Function):
         while S < 512 and M % (S * 2) == 0 and M // (S * 2) >= 1024:
             S *= 2
         gw = torch.bmm(g.view(S, M // S, C).transpose(1, 2), cols.view(S, M // S, K)).sum(0)
-        return gcols, gw, g.sum(0)
+        return gcols, gw, _colsum(g)
 
 
 N_PART = 256  # partial gradient vectors of the conv backward kernel (one per persistent workgroup)
@@ -136,7 +136,7 @@ class _Front9Train(torch.autograd.Function):
         vec = torch.cat([obs_i8[:, 243:245].float(), onehot_i8.float()], dim=1)
         g_mw = _wgrad_splitk(gz.contiguous(), vec)
         return (None, None, tot[n2 + od:n2 + od + od * 27].view(s1), tot[n2 + od + od * 27:], tot[:n2].view(s2), tot[n2:n2 + od],
-                g_mw, gz.sum(0), None)
+                g_mw, _colsum(gz), None)
 
 
 class _LinearSplitK(torch.autograd.Function):
@@ -154,7 +154,17 @@ class _LinearSplitK(torch.autograd.Function):
         x, w = ctx.saved_tensors
         g = g.contiguous()
         gx = torch.matmul(g, w) if ctx.needs_input_grad[0] else None
-        return gx, _wgrad_splitk(g, x), (g.sum(0) if ctx.has_bias else None)
+        return gx, _wgrad_splitk(g, x), (_colsum(g) if ctx.has_bias else None)
+
+
+def _colsum(t2d):
+    """Column sums of a very tall matrix (bias gradients): two stages, so that the first one has thousands of
+    independent outputs instead of a handful (a single at::sum over 81 920 x 10 takes 55 us, this 12 us)."""
+    M = t2d.shape[0]
+    for cand in (256, 128, 64, 32):
+        if M % cand == 0 and M // cand >= 64:
+            return t2d.reshape(cand, M // cand, -1).sum(1).sum(0)
+    return t2d.sum(0)
 
 
 def _wgrad_splitk(g2d, x2d):
