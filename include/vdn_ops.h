@@ -1,0 +1,47 @@
+/*
+ * vdn_ops.h -- C ABI of the TD-error block of VDN.learn (reference policy/vdn.py:104-123), fused.
+ *
+ * Between the Q-networks and the backward pass the reference does, on (episodes B) x (steps T) x (agents n) x
+ * (actions A) tensors:  q_evals = gather(q_evals, u);  q_targets[avail_u_next == 0] = -9999999;  q_targets = max_a;
+ * q_total_* = VDNNet = sum over agents (network/vdn_net.py:5-10);  targets = r + gamma * q_total_target * (1 - terminated);
+ * td_error = targets.detach() - q_total_eval;  mask = 1 - padded;  masked_td_error = mask * td_error;
+ * loss = (masked_td_error ** 2).sum() / mask.sum().  As tensor ops that is ~30 launches of a few microseconds forward and
+ * backward; here it is one launch each way (the two scalar sums stay with the caller).
+ *
+ * Conventions as dmfb_vec.h: plain C types, caller-owned DEVICE buffers, `stream` = hipStream_t as void*, asynchronous,
+ * negative int error codes.  The Q tensors are TIME-MAJOR float32 [T][B][n][A] (what the GRU sequence kernels produce);
+ * the episode tensors are the replay buffer's, chip-major with `t_limit` slots per episode:
+ * u int8[B][t_limit][n][1], r float32[B][t_limit][1], avail_u_next int8[B][t_limit][n][A],
+ * terminated / padded uint8 (bool) [B][t_limit][1].  Only steps t < T are read.
+ */
+#ifndef VDN_OPS_H
+#define VDN_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDN_OK 0
+#define VDN_ERR_BAD_ARG (-1)
+#define VDN_ERR_HIP (-100)
+
+/* d_mtd[b*T + t] = masked_td_error, d_mask[b*T + t] = 1 - padded (float32 [B*T] each); the float operations and their
+ * order are the reference's: gamma * q_total_target, then * (1 - terminated), then r + ...; agents summed in index order. */
+int vdn_td_forward(const float *d_q_eval, const float *d_q_target, const int8_t *d_u, const float *d_r,
+                   const int8_t *d_avail_next, const uint8_t *d_terminated, const uint8_t *d_padded, int32_t B, int32_t T,
+                   int32_t t_limit, int32_t n_agents, int32_t n_actions, float gamma, float *d_mtd, float *d_mask, void *stream);
+
+/* Gradient of  num = sum(masked_td_error ** 2)  w.r.t. the eval network's Q values, scaled by the upstream gradient
+ * *d_grad_num (device scalar):  d_grad_q[t][b][i][a] = -(2 * mtd * mask) * *d_grad_num  if a == u[b][t][i], else 0
+ * (float32 [T][B][n][A], every element written). */
+int vdn_td_backward(const float *d_mtd, const float *d_mask, const int8_t *d_u, const float *d_grad_num, int32_t B, int32_t T,
+                    int32_t t_limit, int32_t n_agents, int32_t n_actions, float *d_grad_q, void *stream);
+
+int vdn_last_hip_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDN_OPS_H */

@@ -26,6 +26,67 @@ def _t(x, device, dtype):
     return x.to(device=device, dtype=dtype)
 
 
+def _episode_slots(t):
+    """Slots per episode of a (B, T', ...) tensor that is a [:, :T'] view of a contiguous (B, slots, ...) one; None if it
+    is laid out any other way."""
+    inner = 1
+    for k in range(t.dim() - 1, 0, -1):
+        if t.stride(k) != inner and t.shape[k] != 1:
+            return None
+        inner *= t.shape[k]
+    per_step = inner // t.shape[1]
+    if t.shape[0] == 1:
+        return t.shape[1]
+    if per_step == 0 or t.stride(0) % per_step or t.stride(0) // per_step < t.shape[1]:
+        return None
+    return t.stride(0) // per_step
+
+
+class _TDLoss(torch.autograd.Function):
+    """The TD-error block of VDN.learn (reference policy/vdn.py:104-123) as one HIP launch each way (include/vdn_ops.h):
+    (time-major Q values of both nets, the sampled episode tensors as the replay buffer stores them) ->
+    num = sum((mask * td_error) ** 2), mask.sum().  Gradient for the eval net's Q values only."""
+
+    @staticmethod
+    def forward(ctx, q_eval_tm, q_target_tm, u, r, avail_next, terminated, padded, T, gamma):
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.vdn_ops()
+        vp = C.c_void_p
+        B, n, A = u.shape[0], u.shape[2], avail_next.shape[3]
+        t_limit = _episode_slots(u)  # the tensors may be [:, :T] views of the sampled (B, episode_limit, ...) tensors
+        q_eval_tm, q_target_tm = q_eval_tm.contiguous(), q_target_tm.contiguous()
+        mtd = torch.empty(B * T, dtype=torch.float32, device=u.device)
+        mask = torch.empty(B * T, dtype=torch.float32, device=u.device)
+        stream = vp(torch.cuda.current_stream(u.device).cuda_stream)
+        rc = lib.vdn_td_forward(vp(q_eval_tm.data_ptr()), vp(q_target_tm.data_ptr()), vp(u.data_ptr()), vp(r.data_ptr()),
+                                vp(avail_next.data_ptr()), vp(terminated.data_ptr()), vp(padded.data_ptr()), B, T, t_limit, n, A,
+                                float(gamma), vp(mtd.data_ptr()), vp(mask.data_ptr()), stream)
+        if rc != 0:
+            raise RuntimeError('vdn_td_forward failed: %d (hip %d)' % (rc, lib.vdn_last_hip_error()))
+        ctx.save_for_backward(mtd, mask, u)
+        ctx.dims = (B, T, t_limit, n, A)
+        num, mask_sum = (mtd * mtd).sum(), mask.sum()
+        ctx.mark_non_differentiable(mask_sum)
+        return num, mask_sum
+
+    @staticmethod
+    def backward(ctx, g_num, _g_mask):
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.vdn_ops()
+        vp = C.c_void_p
+        mtd, mask, u = ctx.saved_tensors
+        B, T, t_limit, n, A = ctx.dims
+        gq = torch.empty((T, B * n, A), dtype=torch.float32, device=u.device)
+        g = g_num.reshape(1).to(torch.float32).contiguous()
+        rc = lib.vdn_td_backward(vp(mtd.data_ptr()), vp(mask.data_ptr()), vp(u.data_ptr()), vp(g.data_ptr()), B, T, t_limit, n, A,
+                                 vp(gq.data_ptr()), vp(torch.cuda.current_stream(u.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('vdn_td_backward failed: %d (hip %d)' % (rc, lib.vdn_last_hip_error()))
+        return gq, None, None, None, None, None, None, None, None
+
+
 class VDN:
     def __init__(self, args):
         self.args = args
@@ -155,6 +216,20 @@ class VDN:
         dev, T, n = self.device, max_episode_len, self.n_agents
         episode_num = batch['o'].shape[0]
         self.init_hidden(episode_num)
+        if self._td_fused_ok(batch):
+            # replay-buffer tensors on the GPU: Q values stay time-major, the TD block is one launch each way
+            q_e, q_t = self.get_q_values(batch, T, time_major=True)
+            num, mask_sum = _TDLoss.apply(q_e, q_t, batch['u'], batch['r'], batch['avail_u_next'], batch['terminated'],
+                                          batch['padded'], T, self.args.gamma)
+            self.optimizer.zero_grad()
+            if self.dist:
+                num.backward()
+                total = self._allreduce_grads(mask_sum)
+                loss = num.detach() / total
+            else:
+                loss = num / mask_sum
+                loss.backward()
+            return self._step_and_sync(loss, train_step)
         u = _t(batch['u'], dev, torch.long)[:, :T]
         r = _t(batch['r'], dev, torch.float32)[:, :T]
         avail_u_next = _t(batch['avail_u_next'], dev, torch.float32)[:, :T]
@@ -182,6 +257,10 @@ class VDN:
         else:
             loss = (masked_td_error ** 2).sum() / mask.sum()
             loss.backward()
+        return self._step_and_sync(loss, train_step)
+
+    def _step_and_sync(self, loss, train_step):
+        """clip_grad_norm_, optimizer step, hard target sync every target_update_cycle learns (policy/vdn.py:125-132)."""
         self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.eval_parameters, self.args.grad_norm_clip)
         self.optimizer.step()
         self.last_loss = loss.detach()
@@ -190,6 +269,21 @@ class VDN:
             self.target_rnn.load_state_dict(self.eval_rnn.state_dict())
             self.target_vdn_net.load_state_dict(self.eval_vdn_net.state_dict())
         return self.last_loss
+
+    def _td_fused_ok(self, batch):
+        """The fused TD block (include/vdn_ops.h) applies to what ReplayBuffer.sample hands over on the GPU: device tensors
+        in the buffer's dtypes, and networks with the time-major sequence path; the mixer must be the parameter-free VDN sum."""
+        want = {'u': torch.int8, 'r': torch.float32, 'avail_u_next': torch.int8, 'terminated': torch.bool, 'padded': torch.bool}
+        slots = set()
+        for key, dt in want.items():
+            t = batch.get(key)
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dt and t.dim() >= 3):
+                return False
+            slots.add(_episode_slots(t))
+        if len(slots) != 1 or None in slots:
+            return False
+        return (hasattr(self.eval_rnn, 'recurrent_seq') and self.args.alg == 'vdn' and batch['avail_u_next'].shape[3] <= 127
+                and len(list(self.eval_vdn_net.parameters())) == 0)
 
     def _sequence(self, batch, T):
         """Inputs for t = 0..T (policy/vdn.py:134-165): obs_seq[t] = o[:,0] if t == 0 else
@@ -226,7 +320,9 @@ class VDN:
             x = torch.cat([x, la_rows.float()], dim=1)
         return net.features(x)
 
-    def get_q_values(self, batch, max_episode_len):
+    def get_q_values(self, batch, max_episode_len, time_major=False):
+        """(q_evals, q_targets) as (B, T, n, A) like the reference (policy/vdn.py:167-203); time_major=True returns the
+        (T, B*n, A) tensors the GRU sequence kernels produce, without the transposing views (None if that path is not taken)."""
         T, n = max_episode_len, self.n_agents
         B = batch['o'].shape[0]
         obs_seq, la = self._sequence(batch, T)
@@ -244,7 +340,11 @@ class VDN:
             with torch.no_grad():
                 q_t, self.target_hidden = self.target_rnn.recurrent_seq(x_tgt, self.target_hidden)
             # (T, B*n, A) -> (B, T, n, A)
+            if time_major:
+                return q_e, q_t
             return (q_e.view(T, B, n, -1).permute(1, 0, 2, 3), q_t.view(T, B, n, -1).permute(1, 0, 2, 3))
+        if time_major:
+            return None
         q_evals, q_targets = [], []
         for t in range(T):
             q_eval, self.eval_hidden = self.eval_rnn.recurrent(x_eval[t], self.eval_hidden)

@@ -1,0 +1,90 @@
+"""The fused TD-error block (include/vdn_ops.h, policy/vdn.py:_TDLoss) against the tensor-op restatement of the reference's
+lines (policy/vdn.py:104-123) that `VDN.learn` keeps as its fallback: same sampled batch, same weights -> same loss, same
+gradient norm, same updated weights.  Floating point: the two paths form the same products and sums up to the order of the
+n-agent sum and of the final scalar reductions, tolerance 2e-6 relative on loss / norm and 1e-6 absolute on the weights."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(name):
+    from marl_dmfb_amd.common.arguments import make_args
+    from marl_dmfb_amd.train import Trainer
+    if name == 'dmfb':
+        from marl_dmfb_amd.env.dmfb import VecDMFB
+        env = VecDMFB(10, 10, 4, fov=9, n_envs=192, seed=21, device='cuda:0')
+        kw = {}
+    else:
+        from marl_dmfb_amd.env.meda import VecMEDA
+        env = VecMEDA(30, 30, 4, fov=19, n_envs=48, seed=21, device='cuda:0', version=2)
+        kw = dict(name='meda', drop_num=4, width=30, length=30, fov=19)
+    torch.manual_seed(9)
+    args = make_args(device='cuda:0', n_envs=env.n_envs, batch_size=64, train_time=1, buffer_size=4 * env.n_envs, anneal_steps=5000,
+                     **kw, **env.get_env_info())
+    return Trainer(env, args)
+
+
+@pytest.mark.parametrize('name', ['dmfb', 'meda'])
+def test_fused_td_block_equals_tensor_op_path(name):
+    tr = _trainer(name)
+    for _ in range(2):
+        out = tr.rolloutWorker.generate_episode()
+        tr.buffer.store_episode(out[4])
+    # an untrained policy never finishes early: cut a third of the stored episodes short by hand (padded from step k on,
+    # terminated from k-1 on, as the rollout would have written them) so that the mask and the (1 - terminated) factor matter
+    bufs = tr.buffer.buffers
+    S, Tl = bufs['padded'].shape[0], bufs['padded'].shape[1]
+    for e in range(0, tr.buffer.current_size, 3):
+        k = 3 + (e * 7) % (Tl - 4)
+        bufs['padded'][e, k:] = True
+        bufs['terminated'][e, k - 1:] = True
+    pol = tr.agents.policy
+    ref = copy.deepcopy(pol)    # same weights, same optimizer state
+    ref._td_fused_ok = lambda batch: False
+    for step in range(3):
+        batch = tr.buffer.sample(64)
+        batch_ref = {k: v.clone() for k, v in batch.items()}
+        assert pol._td_fused_ok({k: v[:, :7] for k, v in batch.items()})    # [:, :T] views keep the fused path
+        T = tr.agents._get_max_episode_len(batch)
+        la = tr.agents.train(batch, step)
+        lb = copy.copy(tr.agents)
+        lb.policy = ref
+        lr = lb.train(batch_ref, step)
+        assert float(batch['padded'].float().mean()) > 0.0
+        np.testing.assert_allclose(float(la), float(lr), rtol=2e-6)
+        np.testing.assert_allclose(float(pol.last_grad_norm), float(ref.last_grad_norm), rtol=2e-6)
+        for (ka, pa), (kb, pb) in zip(pol.eval_rnn.state_dict().items(), ref.eval_rnn.state_dict().items()):
+            np.testing.assert_allclose(pa.cpu().numpy(), pb.cpu().numpy(), rtol=0, atol=1e-6, err_msg='%s step %d' % (ka, step))
+
+
+def test_td_kernels_against_restated_formula():
+    """The two kernels alone on random tensors: masked TD error and the gradient w.r.t. the eval Q values."""
+    from marl_dmfb_amd.policy.vdn import _TDLoss
+    torch.manual_seed(3)
+    B, T, Tl, n, A = 37, 11, 16, 5, 9
+    q_e = torch.randn(T, B * n, A, device='cuda', requires_grad=True)
+    q_t = torch.randn(T, B * n, A, device='cuda')
+    u = torch.randint(0, A, (B, Tl, n, 1), device='cuda').to(torch.int8)
+    r = torch.randn(B, Tl, 1, device='cuda')
+    av = (torch.rand(B, Tl, n, A, device='cuda') < 0.8).to(torch.int8)
+    av[..., 0] = 1
+    term = torch.rand(B, Tl, 1, device='cuda') < 0.1
+    pad = torch.rand(B, Tl, 1, device='cuda') < 0.3
+    num, msum = _TDLoss.apply(q_e, q_t, u[:, :T], r[:, :T], av[:, :T], term[:, :T], pad[:, :T], T, 0.99)
+    (num / msum).backward()
+    qe = q_e.detach().double().view(T, B, n, A).permute(1, 0, 2, 3).requires_grad_(True)
+    qt = q_t.double().view(T, B, n, A).permute(1, 0, 2, 3)
+    chosen = torch.gather(qe, 3, u[:, :T].long()).squeeze(3).sum(2, keepdim=True)
+    tmax = qt.masked_fill(av[:, :T] == 0, -9999999).max(3)[0].sum(2, keepdim=True)
+    mask = 1 - pad[:, :T].double()
+    td = (r[:, :T].double() + 0.99 * tmax * (1 - term[:, :T].double())) - chosen
+    num_ref = ((mask * td) ** 2).sum()
+    (num_ref / mask.sum()).backward()
+    np.testing.assert_allclose(float(num.detach()), float(num_ref.detach()), rtol=1e-5)
+    assert float(msum) == float(mask.sum())
+    g_ref = qe.grad.permute(1, 0, 2, 3).reshape(T, B * n, A)
+    np.testing.assert_allclose(q_e.grad.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-5, atol=1e-7)
