@@ -89,6 +89,8 @@ class _TDLoss(torch.autograd.Function):
 
 class VDN:
     def __init__(self, args):
+        from ..common import gemm_tuning
+        gemm_tuning.enable()  # before the first GEMM: shipped rocBLAS / hipBLASLt solution choices (no on-line tuning)
         self.args = args
         self.n_actions = args.n_actions
         self.n_agents = args.n_agents
