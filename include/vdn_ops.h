@@ -28,10 +28,15 @@ extern "C" {
 #define VDN_ERR_HIP (-100)
 
 /* d_mtd[b*T + t] = masked_td_error, d_mask[b*T + t] = 1 - padded (float32 [B*T] each); the float operations and their
- * order are the reference's: gamma * q_total_target, then * (1 - terminated), then r + ...; agents summed in index order. */
+ * order are the reference's: gamma * q_total_target, then * (1 - terminated), then r + ...; agents summed in index order.
+ * An action outside [0, n_actions) (torch.gather raises on it, policy/vdn.py:106) is never used as an index: the slot's
+ * d_mtd becomes NaN (so the loss and every gradient of that learn are NaN) and, when d_bad_actions is not NULL, the int32
+ * device counter it points to is incremented once per such (episode, step) -- the call is asynchronous, so the caller reads
+ * the counter when it next synchronises. */
 int vdn_td_forward(const float *d_q_eval, const float *d_q_target, const int8_t *d_u, const float *d_r,
                    const int8_t *d_avail_next, const uint8_t *d_terminated, const uint8_t *d_padded, int32_t B, int32_t T,
-                   int32_t t_limit, int32_t n_agents, int32_t n_actions, float gamma, float *d_mtd, float *d_mask, void *stream);
+                   int32_t t_limit, int32_t n_agents, int32_t n_actions, float gamma, float *d_mtd, float *d_mask,
+                   int32_t *d_bad_actions, void *stream);
 
 /* Gradient of  num = sum(masked_td_error ** 2)  w.r.t. the eval network's Q values, scaled by the upstream gradient
  * *d_grad_num (device scalar):  d_grad_q[t][b][i][a] = -(2 * mtd * mask) * *d_grad_num  if a == u[b][t][i], else 0

@@ -183,7 +183,7 @@ def vdn_ops():
     if getattr(lib, '_typed', False):
         return lib
     vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
-    lib.vdn_td_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]
+    lib.vdn_td_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]
     lib.vdn_td_backward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.vdn_last_hip_error.argtypes = []
     lib._typed = True

@@ -52,8 +52,6 @@ struct DevCfg {
     int ucap;            // steps a chip's usage log holds (= max_step), see DevPtrs::ulog
     int lstride;         // uint16 entries per logged step: 16 (one aligned 32-byte sector per step, unused ones 0xFFFF)
     int hist_bytes;      // LDS bytes of one wave's usage histogram, 0 = chip too large for LDS (global-atomic path)
-    int compact;         // 1: the maps are the generator's own (never replaced through set_map): the transition may rebuild a
-                         // cell's health from DevPtrs::kmap instead of gathering the float64 map (see health_of)
     double per_healthy;
 };
 
@@ -76,6 +74,11 @@ struct DevPtrs {
     // chip: 200 bytes, under two 128-byte lines) instead of one float64 from a 128-byte line each.  A saturated count
     // (health <= 0.6^15 of a degrading cell, or 15+ degradations) falls back to the float64 map for that cell.
     uint8_t *kmap;
+    // dflags[0] != 0: the maps are the generator's own (never replaced through set_map), so the transition may rebuild a
+    // cell's health from `kmap` instead of gathering the float64 map.  A DEVICE word, written by stream-ordered one-thread
+    // launches (dmfb_vec_set_map / reset(new)), so that a transition captured into a HIP graph before a map was injected
+    // sees the switch when it is replayed (a by-value kernel argument would be frozen at capture time).
+    const int *dflags;
     const int8_t *zoom;  // [2][511] direction zoom table
     uint32_t *blocks;    // [n_blocks][E] x_min | x_max<<8 | y_min<<16 | y_max<<24, or nullptr
     // Observation tables, copied into LDS by every workgroup that builds observations (table_words() 8-byte words):
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
             }
             double prob[N], draw[N];
             const bool use_draws = MAPS || a.uniforms != nullptr;
-            const bool compact = MAPS && c.compact;
+            const bool compact = MAPS && p.dflags[0] != 0;
             uint8_t kcnt[N];
 
             if (use_draws) {

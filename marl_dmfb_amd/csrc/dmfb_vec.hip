@@ -107,6 +107,8 @@ __global__ void k_get_state(DevCfg c, DevPtrs p, int32_t *pos, int32_t *dist, in
     if (cons) cons[e] = (int64_t)p.st[(size_t)(2 * np + 1) * E + e];
 }
 
+__global__ void k_set_word(int *dst, int v) { *dst = v; }  // DevPtrs::dflags, stream-ordered and graph-capturable
+
 __global__ void k_get_map(size_t total, const double *health, const double *degrade, const uint16_t *usage, int which,
                           double *out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -169,6 +171,7 @@ struct dmfb_vec {
     int8_t zoom_host[2 * 511];
     int8_t *zoom_dev = nullptr;
     unsigned long long *band_dev = nullptr;  // DevPtrs::band
+    int *dflags_dev = nullptr;               // DevPtrs::dflags
     size_t bytes = 0;
     int T_fused = 16;    // chips per workgroup of the fused step+observe launch (<= 64)
     int T_obs = 16;      // chips per workgroup of k_observe
@@ -351,7 +354,10 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
         if (const char *v = getenv("DMFB_VEC_LOG_STRIDE")) d.lstride = atoi(v) == 16 ? 16 : n;  // measurement knob: n = packed entries
         CREATE_TRY(hipMalloc(&h->dp.ulog, (size_t)E * d.ucap * d.lstride * 2));
         CREATE_TRY(hipMalloc(&h->dp.kmap, kmap_bytes(cells) * E));
-        d.compact = 1;  // until health or degrade is replaced through dmfb_vec_set_map
+        CREATE_TRY(hipMalloc(&h->dflags_dev, 4));
+        h->dp.dflags = h->dflags_dev;
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, s, h->dflags_dev, 1);  // until health or degrade is replaced (set_map)
+        CREATE_TRY(hipGetLastError());
         d.hist_bytes = (int)cells <= kHistMaxCells ? (int)((cells * 2 + 15) & ~(size_t)15) : 0;
         h->bytes += cells * E * 18 + kmap_bytes(cells) * E + (size_t)E * d.ucap * d.lstride * 2;
     }
@@ -431,7 +437,7 @@ int dmfb_vec_destroy(dmfb_vec *h) {
     DeviceGuard g(h->cfg.device);
     (void)hipFree(h->dp.st); (void)hipFree(h->dp.starts); (void)hipFree(h->dp.health);
     (void)hipFree(h->dp.degrade); (void)hipFree(h->dp.usage); (void)hipFree(h->dp.ulog); (void)hipFree(h->dp.kmap); (void)hipFree(h->zoom_dev); (void)hipFree(h->dp.blocks);
-    (void)hipFree(h->band_dev);
+    (void)hipFree(h->band_dev); (void)hipFree(h->dflags_dev);
     for (int i = 0; i < 2 * dmfb_vec::kTimed; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -448,7 +454,10 @@ int dmfb_vec_reset(dmfb_vec *h, const uint8_t *d_mask, int new_flag, int8_t *d_o
     if (!h) return DMFB_ERR_BAD_ARG;
     DeviceGuard g(h->cfg.device);
     int rc = launch_reset(h, d_mask, new_flag ? 1 : 0, (hipStream_t)stream);
-    if (!rc && new_flag && !d_mask && h->dp.health) h->dc.compact = 1;  // every map is the generator's own again
+    if (!rc && new_flag && !d_mask && h->dp.health) {  // every map is the generator's own again
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, (hipStream_t)stream, h->dflags_dev, 1);
+        HIP_TRY(hipGetLastError());
+    }
     if (rc || !d_obs) return rc;
     return launch_observe(h, d_mask, d_obs, (hipStream_t)stream);
 }
@@ -554,7 +563,10 @@ int dmfb_vec_set_map(dmfb_vec *h, int which, const double *d_buf, void *stream) 
     DeviceGuard g(h->cfg.device);
     const size_t total = (size_t)h->cfg.n_envs * h->cfg.width * h->cfg.length;
     (void)hipGetLastError();  // drop stale errors left by other users of the runtime
-    if (which != DMFB_MAP_USAGE) h->dc.compact = 0;  // health / degrade no longer follow from the generator: gather the float64 map
+    if (which != DMFB_MAP_USAGE) {  // health / degrade no longer follow from the generator: gather the float64 map
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, (hipStream_t)stream, h->dflags_dev, 0);
+        HIP_TRY(hipGetLastError());
+    }
     if (which == DMFB_MAP_USAGE) {  // pending log entries belong to the map that is being replaced: fold them in first
         hipLaunchKernelGGL(k_flush_usage, dim3((h->cfg.n_envs + (kBlock / kWave) - 1) / (kBlock / kWave)), dim3(kBlock), hist_lds(h),
                            (hipStream_t)stream, h->dc, h->dp);

@@ -13,15 +13,18 @@ thread_local int g_last = 0;
 __global__ __launch_bounds__(256) void k_td_forward(const float *__restrict__ qe, const float *__restrict__ qt, const int8_t *__restrict__ u,
                                                     const float *__restrict__ r, const int8_t *__restrict__ avail,
                                                     const uint8_t *__restrict__ term, const uint8_t *__restrict__ padded, int B, int T,
-                                                    int Tl, int n, int A, float gamma, float *__restrict__ mtd, float *__restrict__ maskf) {
+                                                    int Tl, int n, int A, float gamma, float *__restrict__ mtd, float *__restrict__ maskf,
+                                                    int32_t *__restrict__ bad) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * T) return;
     const int b = idx / T, t = idx - b * T;
     const size_t ep = (size_t)b * Tl + t;            // slot in the chip-major episode tensors
     const size_t q0 = ((size_t)t * B + b) * n * A;   // row block in the time-major Q tensors
     float qe_tot = 0.0f, qt_tot = 0.0f;
+    bool ok = true;
     for (int i = 0; i < n; ++i) {
-        const int a_taken = (int)u[ep * n + i];
+        int a_taken = (int)u[ep * n + i];
+        if ((unsigned)a_taken >= (unsigned)A) { ok = false; a_taken = 0; }  // torch.gather raises here; never read out of bounds
         qe_tot = qe_tot + qe[q0 + (size_t)i * A + a_taken];
         float m = -3.4e38f;
         for (int a = 0; a < A; ++a) {
@@ -33,8 +36,9 @@ __global__ __launch_bounds__(256) void k_td_forward(const float *__restrict__ qe
     const float not_term = 1.0f - (term[ep] ? 1.0f : 0.0f);
     const float target = r[ep] + (gamma * qt_tot) * not_term;
     const float mk = 1.0f - (padded[ep] ? 1.0f : 0.0f);
-    mtd[idx] = mk * (target - qe_tot);
+    mtd[idx] = ok ? mk * (target - qe_tot) : __builtin_nanf("");  // an action outside [0, A) poisons the loss (loud) ...
     maskf[idx] = mk;
+    if (!ok && bad) atomicAdd(bad, 1);                            // ... and is counted for vdn_td_forward's caller
 }
 
 // one thread per (t, b, i) row of the time-major gradient
@@ -48,8 +52,9 @@ __global__ __launch_bounds__(256) void k_td_backward(const float *__restrict__ m
     const int b = (int)(tb % B), t = (int)(tb / B);
     const int idx = b * T + t;
     const float d = -((2.0f * mtd[idx]) * maskf[idx]) * g[0];
-    const int a_taken = (int)u[((size_t)b * Tl + t) * n + i];
-    for (int a = 0; a < A; ++a) gq[row * A + a] = a == a_taken ? d : 0.0f;
+    const int a_taken = (int)u[((size_t)b * Tl + t) * n + i];  // outside [0, A): mtd is NaN for the slot, so d is NaN: keep it visible
+    const bool bad_a = (unsigned)a_taken >= (unsigned)A;
+    for (int a = 0; a < A; ++a) gq[row * A + a] = (bad_a || a == a_taken) ? d : 0.0f;
 }
 
 }  // namespace
@@ -58,7 +63,8 @@ extern "C" {
 
 int vdn_td_forward(const float *d_q_eval, const float *d_q_target, const int8_t *d_u, const float *d_r,
                    const int8_t *d_avail_next, const uint8_t *d_terminated, const uint8_t *d_padded, int32_t B, int32_t T,
-                   int32_t t_limit, int32_t n_agents, int32_t n_actions, float gamma, float *d_mtd, float *d_mask, void *stream) {
+                   int32_t t_limit, int32_t n_agents, int32_t n_actions, float gamma, float *d_mtd, float *d_mask, int32_t *d_bad_actions,
+                   void *stream) {
     if (!d_q_eval || !d_q_target || !d_u || !d_r || !d_avail_next || !d_terminated || !d_padded || !d_mtd || !d_mask || B < 0 ||
         T < 1 || t_limit < T || n_agents < 1 || n_actions < 1 || n_actions > 127)
         return VDN_ERR_BAD_ARG;
@@ -66,7 +72,7 @@ int vdn_td_forward(const float *d_q_eval, const float *d_q_target, const int8_t 
     (void)hipGetLastError();
     const int total = B * T;
     hipLaunchKernelGGL(k_td_forward, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_q_eval, d_q_target, d_u, d_r,
-                       d_avail_next, d_terminated, d_padded, B, T, t_limit, n_agents, n_actions, gamma, d_mtd, d_mask);
+                       d_avail_next, d_terminated, d_padded, B, T, t_limit, n_agents, n_actions, gamma, d_mtd, d_mask, d_bad_actions);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last = (int)e; return VDN_ERR_HIP; }
     return VDN_OK;

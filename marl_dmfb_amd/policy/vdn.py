@@ -48,7 +48,7 @@ class _TDLoss(torch.autograd.Function):
     num = sum((mask * td_error) ** 2), mask.sum().  Gradient for the eval net's Q values only."""
 
     @staticmethod
-    def forward(ctx, q_eval_tm, q_target_tm, u, r, avail_next, terminated, padded, T, gamma):
+    def forward(ctx, q_eval_tm, q_target_tm, u, r, avail_next, terminated, padded, T, gamma, bad=None):
         import ctypes as C
         from .. import _lib
         lib = _lib.vdn_ops()
@@ -61,7 +61,8 @@ class _TDLoss(torch.autograd.Function):
         stream = vp(torch.cuda.current_stream(u.device).cuda_stream)
         rc = lib.vdn_td_forward(vp(q_eval_tm.data_ptr()), vp(q_target_tm.data_ptr()), vp(u.data_ptr()), vp(r.data_ptr()),
                                 vp(avail_next.data_ptr()), vp(terminated.data_ptr()), vp(padded.data_ptr()), B, T, t_limit, n, A,
-                                float(gamma), vp(mtd.data_ptr()), vp(mask.data_ptr()), stream)
+                                float(gamma), vp(mtd.data_ptr()), vp(mask.data_ptr()),
+                                None if bad is None else vp(bad.data_ptr()), stream)
         if rc != 0:
             raise RuntimeError('vdn_td_forward failed: %d (hip %d)' % (rc, lib.vdn_last_hip_error()))
         ctx.save_for_backward(mtd, mask, u)
@@ -84,7 +85,7 @@ class _TDLoss(torch.autograd.Function):
                                  vp(gq.data_ptr()), vp(torch.cuda.current_stream(u.device).cuda_stream))
         if rc != 0:
             raise RuntimeError('vdn_td_backward failed: %d (hip %d)' % (rc, lib.vdn_last_hip_error()))
-        return gq, None, None, None, None, None, None, None, None
+        return gq, None, None, None, None, None, None, None, None, None
 
 
 class VDN:
@@ -152,6 +153,7 @@ class VDN:
         self.last_loss = None
         self.last_grad_norm = None
         self._flat = None
+        self._td_bad = None  # device counter of (episode, step) slots whose action was outside [0, n_actions) (include/vdn_ops.h)
         # scalars a caller wants summed over the ranks without a collective of their own (Trainer: the env-step count of the
         # round): float32 tensor set before learn(); the next gradient all-reduce carries it and leaves the sums here
         self.ride_along = None
@@ -221,8 +223,10 @@ class VDN:
         if self._td_fused_ok(batch):
             # replay-buffer tensors on the GPU: Q values stay time-major, the TD block is one launch each way
             q_e, q_t = self.get_q_values(batch, T, time_major=True)
+            if self._td_bad is None:
+                self._td_bad = torch.zeros(1, dtype=torch.int32, device=dev)
             num, mask_sum = _TDLoss.apply(q_e, q_t, batch['u'], batch['r'], batch['avail_u_next'], batch['terminated'],
-                                          batch['padded'], T, self.args.gamma)
+                                          batch['padded'], T, self.args.gamma, self._td_bad)
             self.optimizer.zero_grad()
             if self.dist:
                 num.backward()
@@ -260,6 +264,16 @@ class VDN:
             loss = (masked_td_error ** 2).sum() / mask.sum()
             loss.backward()
         return self._step_and_sync(loss, train_step)
+
+    def check_td_inputs(self):
+        """Raises if any learn since the last call met an action outside [0, n_actions) -- the input torch.gather raises on in
+        the reference (policy/vdn.py:106).  The fused TD kernel never indexes with such a value; it poisons that learn's loss
+        with NaN and counts the slot.  Reading the counter synchronises, so this runs at checkpoints (save_model), not per learn."""
+        if self._td_bad is not None:
+            bad = int(self._td_bad.item())
+            if bad:
+                self._td_bad.zero_()
+                raise RuntimeError('VDN.learn: %d (episode, step) slots with an action outside [0, %d)' % (bad, self.n_actions))
 
     def _step_and_sync(self, loss, train_step):
         """clip_grad_norm_, optimizer step, hard target sync every target_update_cycle learns (policy/vdn.py:125-132)."""
@@ -364,6 +378,7 @@ class VDN:
     def save_model(self, train_step=None):
         """File names of the reference (policy/vdn.py:205-218): {i}_[{k}_]rnn_net_params.pkl and the
         (empty) mixer state dict."""
+        self.check_td_inputs()
         if not os.path.exists(self.model_dir):
             os.makedirs(self.model_dir)
         i = self.args.ith_run

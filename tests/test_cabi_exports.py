@@ -116,5 +116,5 @@ def test_vdn_ops_library_exports():
     for n in names:
         assert hasattr(lib, n)
     # argument guards run on the host before anything touches the GPU
-    assert lib.vdn_td_forward(None, None, None, None, None, None, None, 4, 3, 8, 2, 5, 0.99, None, None, None) == -1
+    assert lib.vdn_td_forward(None, None, None, None, None, None, None, 4, 3, 8, 2, 5, 0.99, None, None, None, None) == -1
     assert lib.vdn_td_backward(None, None, None, None, 4, 3, 8, 2, 5, None, None) == -1

@@ -66,3 +66,30 @@ def test_graph_rollout_equals_eager_rollout(name):
     eb = b.rolloutWorker._generate_episode()
     for k in range(4):
         assert torch.equal(ea[k], eb[k]), ('eval stat', k)
+
+
+def test_graph_replay_sees_a_map_injected_after_capture():
+    """A transition captured into a HIP graph while the chips' health still followed from the generator (4-bit degrade counts,
+    DESIGN.md section 2) must gather the float64 map once one is injected with set_map -- the switch lives in device memory
+    (DevPtrs::dflags), not in a by-value kernel argument frozen at capture.  Injected health 0.0 everywhere: no droplet may move
+    (`u <= health` never holds, dmfb.py:335), so every chip plays to the step limit and fails; the eager twin agrees."""
+    from marl_dmfb_amd.agent.agent import Agents
+    from marl_dmfb_amd.common.arguments import make_args
+    from marl_dmfb_amd.common.rollout import Evaluator
+    from marl_dmfb_amd.env.dmfb import VecDMFB
+    outs = []
+    for use_graph in (True, False):
+        env = VecDMFB(10, 10, 4, fov=9, n_envs=128, seed=3, device='cuda:0', b_degrade=True, per_degrade=1.0)
+        torch.manual_seed(2)
+        args = make_args(device='cuda:0', n_envs=env.n_envs, **env.get_env_info())
+        ev = Evaluator(env, Agents(args), args.episode_limit)
+        ev.use_graph = use_graph
+        first = ev._generate_episode()                # graph side: warm-up episode + capture + one replay
+        if not use_graph:
+            first = ev._generate_episode()            # same number of episodes on the eager side
+        env.set_map('health', torch.zeros((128, 10, 10), dtype=torch.float64, device='cuda:0'))
+        second = ev._generate_episode()
+        outs.append((first, second))
+        assert int(second[3].sum()) == 0 and int((second[1] != args.episode_limit).sum()) == 0, 'droplets moved on dead electrodes'
+    for k in range(4):
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), ('stat after set_map', k)

@@ -88,3 +88,40 @@ def test_td_kernels_against_restated_formula():
     assert float(msum) == float(mask.sum())
     g_ref = qe.grad.permute(1, 0, 2, 3).reshape(T, B * n, A)
     np.testing.assert_allclose(q_e.grad.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_action_outside_range_is_loud_not_out_of_bounds():
+    """An action index outside [0, A) in the sampled batch: torch.gather raises on it in the reference (policy/vdn.py:106).
+    The fused kernel must not index with it: the slot's masked TD error becomes NaN (so that learn's loss is NaN), the slot
+    is counted, and VDN.check_td_inputs (run by save_model) raises."""
+    from marl_dmfb_amd.policy.vdn import _TDLoss
+    torch.manual_seed(4)
+    B, T, n, A = 9, 6, 4, 5
+    q_e = torch.randn(T, B * n, A, device='cuda', requires_grad=True)
+    q_t = torch.randn(T, B * n, A, device='cuda')
+    u = torch.randint(0, A, (B, T, n, 1), device='cuda').to(torch.int8)
+    u[2, 3, 1, 0] = A          # one past the end
+    u[5, 0, 0, 0] = -3         # negative
+    r = torch.randn(B, T, 1, device='cuda')
+    av = torch.ones(B, T, n, A, dtype=torch.int8, device='cuda')
+    flags = torch.zeros(B, T, 1, dtype=torch.bool, device='cuda')
+    bad = torch.zeros(1, dtype=torch.int32, device='cuda')
+    num, msum = _TDLoss.apply(q_e, q_t, u, r, av, flags, flags, T, 0.99, bad)
+    num.backward()
+    assert int(bad.item()) == 2
+    assert torch.isnan(num).item()
+    g = q_e.grad.view(T, B, n, A)
+    assert torch.isnan(g[3, 2]).all() and torch.isnan(g[0, 5]).all()     # the two poisoned (step, episode) slots
+    ok = torch.ones(T, B, dtype=torch.bool, device='cuda')
+    ok[3, 2] = ok[0, 5] = False
+    assert torch.isfinite(g[ok]).all()
+
+    tr = _trainer('dmfb')
+    out = tr.rolloutWorker.generate_episode()
+    tr.buffer.store_episode(out[4])
+    tr.buffer.buffers['u'][7, 2, 1, 0] = 77
+    batch = {k: v[:16] for k, v in tr.buffer.buffers.items()}
+    tr.agents.train(batch, 0)
+    with pytest.raises(RuntimeError, match='outside'):
+        tr.agents.policy.save_model(0)
+    tr.agents.policy.check_td_inputs()   # the counter was cleared by the raise

@@ -24,6 +24,9 @@ def test_learn_matches_reference_cpu(path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('replay_dtypes', [True, False], ids=['fused_td', 'tensor_op_td'])
 @pytest.mark.parametrize('path', FILES, ids=os.path.basename)
-def test_learn_matches_reference_gpu(path):
-    learn_golden_check(path, 'cuda:0', rtol=1e-5, atol=1e-5)
+def test_learn_matches_reference_gpu(path, replay_dtypes):
+    """fused_td: the batch in the replay buffer's dtypes -> k_td_forward/backward + time-major Q values, i.e. what Trainer.run
+    and bench.py execute; tensor_op_td: the golden's float64 rewards -> the torch TD block.  Both against the reference's numbers."""
+    learn_golden_check(path, 'cuda:0', rtol=1e-5, atol=1e-5, replay_dtypes=replay_dtypes)

@@ -12,7 +12,10 @@ def det_init(module, salt=0.0):
             p.copy_((scale * torch.sin(0.37 * i + 1.7 * k + salt)).to(torch.float32).view_as(p))
 
 
-def learn_golden_check(path, device, rtol, atol):
+def learn_golden_check(path, device, rtol, atol, replay_dtypes=False):
+    """replay_dtypes: hand the batch over exactly as ReplayBuffer.sample does on the GPU (r float32, int8 actions, bool flags) and
+    REQUIRE the shipped learn path (fused TD block + time-major Q values, policy/vdn.py:_td_fused_ok); otherwise the golden's own
+    dtypes (r float64), which take the tensor-op TD block."""
     from marl_dmfb_amd.agent.agent import Agents
     from marl_dmfb_amd.common.arguments import make_args
     g = np.load(path)
@@ -31,6 +34,13 @@ def learn_golden_check(path, device, rtol, atol):
         batch = {k: torch.as_tensor(g[k]).to(device) for k in keys}
         batch['padded'] = batch['padded'].bool()
         batch['terminated'] = batch['terminated'].bool()
+        if replay_dtypes:
+            batch['r'] = batch['r'].float()
+            for k in ('u', 'avail_u', 'avail_u_next', 'u_onehot', 'o', 'o_next'):
+                batch[k] = batch[k].to(torch.int8)
+            assert agents.policy._td_fused_ok(batch), 'the shipped (fused TD) learn path must be the one under test'
+        else:
+            assert not agents.policy._td_fused_ok(batch)
         agents.train(batch, step)
         np.testing.assert_allclose(float(agents.policy.last_grad_norm), g['grad_norm'][step], rtol=rtol)
         for name, p in agents.policy.eval_rnn.named_parameters():

@@ -41,14 +41,15 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
     --sizes 4096,262144 --msizes 65536 --iters 24 --observe > $OUT/pmc_write.log 2>&1
 python3 $REPO/tools/reduce_profiles.py traffic $OUT/pmc_fetch $OUT/pmc_write $SUM/traffic.json $OUT/labels.json
 echo "== write-pattern and counter-calibration probes ==" ; date
-if [ -x $REPO/tools/probe/write_probe_bin ]; then
-  $REPO/tools/probe/write_probe_bin 642 1840 4 > $SUM/write_probe_642MB.txt 2>&1 || true
-  $REPO/tools/probe/write_probe_bin 257 1840 4 > $SUM/write_probe_257MB.txt 2>&1 || true
+make -C $REPO/tools/probe -s bin/write_probe bin/fetch_calib || true   # built from source, never a checked-in binary
+if [ -x $REPO/tools/probe/bin/write_probe ]; then
+  $REPO/tools/probe/bin/write_probe 642 1840 4 > $SUM/write_probe_642MB.txt 2>&1 || true
+  $REPO/tools/probe/bin/write_probe 257 1840 4 > $SUM/write_probe_257MB.txt 2>&1 || true
 fi
-if [ -x $REPO/tools/probe/fetch_calib_bin ]; then
+if [ -x $REPO/tools/probe/bin/fetch_calib ]; then
   rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv \
-      -d $OUT/calib_req -- $REPO/tools/probe/fetch_calib_bin > $OUT/calib_req.log 2>&1 || true
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib_fetch -- $REPO/tools/probe/fetch_calib_bin > $OUT/calib_fetch.log 2>&1 || true
+      -d $OUT/calib_req -- $REPO/tools/probe/bin/fetch_calib > $OUT/calib_req.log 2>&1 || true
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib_fetch -- $REPO/tools/probe/bin/fetch_calib > $OUT/calib_fetch.log 2>&1 || true
   python3 - <<PY > $SUM/fetch_calibration.txt
 import csv, glob, collections
 acc = collections.defaultdict(list)

@@ -157,6 +157,13 @@ def gen_rollout(seed, n_tasks):
 
 
 if __name__ == '__main__':
-    gen_learn('4d_od24', 4, 10, 10, 9, B=6, seed=5)
-    gen_learn('10d_od32', 10, 20, 20, 9, B=3, seed=6)
-    gen_rollout(seed=2, n_tasks=16)
+    which = sys.argv[1:] or ['small', 'b64', 'rollout']
+    if 'small' in which:
+        gen_learn('4d_od24', 4, 10, 10, 9, B=6, seed=5)
+        gen_learn('10d_od32', 10, 20, 20, 9, B=3, seed=6)
+    if 'b64' in which:
+        # 64 episodes x T 40 x 4 droplets = 10 240 rows: crosses the build's split-K weight-gradient (>= 1024 rows), two-stage
+        # column-sum (>= 2048 rows) and multi-block-per-workgroup conv-backward (> 2560 rows) thresholds
+        gen_learn('4d_od24_b64', 4, 10, 10, 9, B=64, seed=7)
+    if 'rollout' in which:
+        gen_rollout(seed=2, n_tasks=16)
