@@ -71,8 +71,11 @@ def parse(argv=None):
                     help='play the rollout eagerly instead of replaying it as a captured HIP graph (the default)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_tiers', action='store_true')
-    ap.add_argument('--cpu_seconds', type=float, default=20.0, help='wall seconds of the cpu_baseline sample')
-    ap.add_argument('--roofline_envs', type=int, default=262144, help='chips per launch of the roofline kernel')
+    ap.add_argument('--cpu_seconds', type=float, default=24.0, help='CPU seconds per process of the cpu_baseline sample (three phases)')
+    ap.add_argument('--roofline_envs', type=int, default=655360,
+                    help='chips per launch of the roofline kernel: 655 360 x 980 B = 642 MB of output, 2.5x the 256 MiB Infinity Cache')
+    ap.add_argument('--roofline_envs_cached', type=int, default=262144,
+                    help='second, cache-assisted batch (257 MB of output) reported as tiers.fov_kernel_cache_resident')
     ap.add_argument('--launch_check', action='store_true',
                     help='rendezvous + collectives only (no GPU work): checks the --gpus N launch plumbing')
     return ap.parse_args(argv)
@@ -231,13 +234,101 @@ def in_loop_step_kernel(trainer, env, n, fov):
             'note': 'launch-latency bound at this batch (SURVEY 8(d) caveat); nothing subtracted'}
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, f32 operands (the reference's arithmetic type)
+
+
+def conv_front_roofline(net, n, fov, rows_list, device):
+    """`roofline_loop`: the dominant kernel of the timed loop, the Q-network front end (conv1+ReLU+conv2+ReLU + vector MLP + concat,
+    network/base_net.py:59-68) as ONE hand-written fp32-MFMA launch, timed alone at the loop's two launch shapes (rollout lock-step
+    rows = chips x droplets; learn rows = episodes x T x droplets).  Useful FLOP per row = 2 x [(fov-2)^2 od 27 + (fov-4)^2 od od 9 +
+    7 x 10] (MACs of conv1, conv2, mlp1); the kernel pads od 24 to two 16-wide tiles, padding is not counted."""
+    od = net.convs[0].out_channels
+    flop_row = 2 * ((fov - 2) ** 2 * od * 27 + (fov - 4) ** 2 * od * od * 9 + 7 * 10)
+    g = torch.Generator(device=device).manual_seed(7)
+    shapes = []
+    for R in rows_list:
+        obs = torch.randint(0, n + 1, (R, 3 * fov * fov + 2), device=device, generator=g, dtype=torch.int8)
+        oh = torch.zeros((R, 5), dtype=torch.int8, device=device)
+        oh[:, 1] = 1
+        with torch.no_grad():
+            if not net._hip_conv_ok(obs):
+                return None
+            for _ in range(5):
+                net._front_features_hip(obs, oh, padded=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(30):
+                net._front_features_hip(obs, oh, padded=True)
+            e1.record()
+            torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 30
+        tf = R * flop_row / us / 1e6
+        shapes.append({'rows_per_launch': R, 'avg_launch_us': round(us, 2), 'achieved': round(tf, 2), 'frac': round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
+    top = shapes[0]
+    return {'bound': 'mfma', 'kernel': 'crnn_mfma::k_conv9_mfma<%d>' % od, 'achieved': top['achieved'], 'peak': FP32_MFMA_PEAK_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': top['frac'], 'dtype': 'fp32 operands and accumulation (v_mfma_f32_16x16x4_f32)',
+            'rows_per_launch': top['rows_per_launch'], 'avg_launch_us': top['avg_launch_us'], 'useful_flop_per_row': flop_row,
+            'other_launch_shapes': shapes[1:],
+            'timing': '30 back-to-back launches between two HIP events on the launch stream (output buffer allocation included)'}
+
+
 # ------------------------------------------------------------------------------------------------
 # cpu_baseline: the reference's loop shape on the host cores (one single-chip process per core)
 # ------------------------------------------------------------------------------------------------
+def _cpu_env_worker(job):
+    """Phases that never call backward(): (a) env only -- C oracle reset/step/observe, uniform random actions; (b) the reference's
+    rollout -- per step n Q-net forwards of batch 1 through Agents.choose_action (common/rollout.py:19-39), torch CPU, ONE thread,
+    no learn.  Such a process opens no GPU device node, so one runs per host core."""
+    import numpy as np
+    cfg, sec_env, sec_roll, seed = job
+    from oracle.dmfb_oracle import DmfbOracle  # cpu_baseline leg: allowed user of oracle/
+    n, fov = cfg['n_agents'], cfg['fov']
+    ora = DmfbOracle(n_envs=1, seed=seed, **cfg)
+    rng = np.random.default_rng(seed)
+    t0 = time.perf_counter()
+    env_steps = 0
+    ora.reset()
+    while time.perf_counter() - t0 < sec_env:
+        r, d, c, s = ora.step(rng.integers(0, 5, (1, n)).astype(np.int32))
+        if d.all():
+            ora.reset()
+        ora.observe()
+        env_steps += 1
+    t_env = time.perf_counter() - t0
+    played, t_roll = 0, 0.0
+    if sec_roll > 0:
+        torch.set_num_threads(1)
+        from marl_dmfb_amd.agent.agent import Agents
+        from marl_dmfb_amd.common.arguments import make_args
+        T = 2 * (cfg['width'] + cfg['length'])
+        a = make_args(drop_num=n, width=cfg['width'], length=cfg['length'], fov=fov, cuda=False, device='cpu', n_actions=5, n_agents=n,
+                      obs_shape=(3, fov, fov, 2, 3 * fov * fov + 2), episode_limit=T)
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        agents = Agents(a)
+        avail = np.ones(5)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < sec_roll:
+            ora.reset()
+            obs = ora.observe()[0]
+            agents.policy.init_hidden(1)
+            last = np.zeros((n, 5))
+            for t in range(T):
+                acts = [int(agents.choose_action(obs[i], last[i], i, avail, 0.5)) for i in range(n)]
+                r, d, c, s = ora.step(np.asarray(acts, np.int32)[None])
+                obs, last = ora.observe()[0], np.eye(5)[acts]
+                played += 1
+                if d.all():
+                    break
+        t_roll = time.perf_counter() - t0
+    return {'env_steps': env_steps, 't_env': t_env, 'played': played, 't_roll': t_roll}
+
+
 def _cpu_worker(job):
-    """One host core: a single chip (C oracle behind the reference-shaped reset/step protocol), the reference's
+    """The full loop on one host core: a single chip (C oracle behind the reference-shaped reset/step protocol), the reference's
     rollout (n Q-net forwards of batch size 1 per step through Agents.choose_action, common/rollout.py:19-39) and
-    VDN.learn on torch CPU with ONE thread.  Returns counts and times of three phases."""
+    VDN.learn on torch CPU with ONE thread, at the GPU run's learn/collect ratio."""
     import numpy as np
     torch.set_num_threads(1)
     from oracle.dmfb_oracle import DmfbOracle  # cpu_baseline leg: allowed user of oracle/
@@ -254,26 +345,13 @@ def _cpu_worker(job):
     agents = Agents(a)
     ora = DmfbOracle(n_envs=1, seed=seed, **cfg)
     rng = np.random.default_rng(seed)
-    # phase 1: env only -- reset + step + observe, uniform random actions
-    t0 = time.perf_counter()
-    env_steps = 0
-    ora.reset()
-    while time.perf_counter() - t0 < seconds * 0.15:
-        r, d, c, s = ora.step(rng.integers(0, 5, (1, n)).astype(np.int32))
-        if d.all():
-            ora.reset()
-        ora.observe()
-        env_steps += 1
-    t_env = time.perf_counter() - t0
-    # phase 2+3: the full loop -- episodes through choose_action (B = 1 per agent), learns at the GPU run's
-    # learn/collect ratio
     avail = np.ones(5)
     episodes = []
     t0 = time.perf_counter()
     played = learn_s = 0.0
     learns = 0
     eps = 0.5
-    while time.perf_counter() - t0 < seconds * 0.85:
+    while time.perf_counter() - t0 < seconds:
         ora.reset()
         obs = ora.observe()[0]
         agents.policy.init_hidden(1)
@@ -304,7 +382,7 @@ def _cpu_worker(job):
             learn_s += time.perf_counter() - tl
             episodes = episodes[-4 * collect_per_learn:]
     t_full = time.perf_counter() - t0
-    return {'env_steps': env_steps, 't_env': t_env, 'played': played, 't_full': t_full, 'learns': learns, 'learn_s': learn_s}
+    return {'played': played, 't_full': t_full, 'learns': learns, 'learn_s': learn_s}
 
 
 def _cpu_model():
@@ -317,31 +395,85 @@ def _cpu_model():
     return 'unknown'
 
 
+def host_cores():
+    """Cores this process may actually use: the scheduler affinity mask, capped by a cgroup CPU quota when one is set."""
+    try:
+        c = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        c = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    c = min(c, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    c = min(c, max(1, int(q / int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read()))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, c)
+
+
 def cpu_baseline(cfg, a):
-    """The reference's own loop shape timed on the host: one single-threaded process per core, each a single chip +
-    B=1 Q-net forwards + VDN.learn.  Env = the C oracle (kind "port"; the reference's Python env cannot travel to the
-    GPU box), so the env share is a generous stand-in: the reference's Python DMFBenv steps ~2.6e3/s per core
-    (BASELINE.md).  Five processes, not one per host core: torch's autograd engine opens the GPU device nodes in
-    every process that calls backward() -- also on CPU tensors, whatever *_VISIBLE_DEVICES says (tools/probe/
-    gpu_open_probe.py) -- and the GPU box admits six processes with the GPU open (this one + five)."""
+    """The reference's own loop shape timed on the host, one single-threaded single-chip process per core.
+    Env = the C oracle (kind "port"; the reference's Python env cannot travel to the GPU box), so the env share is a generous
+    stand-in: the reference's Python DMFBenv steps ~2.6e3/s per core.
+    Phases: env-only and rollout (no learn) run on EVERY host core -- they never call backward(); the full loop with VDN.learn
+    runs on five processes, because torch's autograd engine opens the GPU device nodes in every process that calls backward()
+    (on CPU tensors too, whatever *_VISIBLE_DEVICES says: tools/probe/gpu_open_probe.py) and the GPU box admits six processes
+    with the GPU open (this one + five).  `value` is the measured full loop on those five cores; `whole_host_loop_estimate`
+    combines the whole-host rollout rate with the per-core learn cost measured there."""
     import multiprocessing as mp
-    cores = max(1, min(5, os.cpu_count() or 1))
+    ctx = mp.get_context('spawn')  # never fork a process that holds a GPU context
+    sec = float(a.cpu_seconds)
+    cores_all = min(host_cores(), int(os.environ.get('BENCH_CPU_MAX_PROCS', '64')))
     sampled_per_collected = a.train_time * a.batch_size / float(a.n_envs)   # the GPU run's learn/collect ratio
     learn_batch = 32
     collect_per_learn = max(1, int(round(learn_batch / max(sampled_per_collected, 1e-9))))
-    ctx = mp.get_context('spawn')  # never fork a process that holds a GPU context
-    jobs = [(cfg, float(a.cpu_seconds), 100 + k, collect_per_learn, learn_batch) for k in range(cores)]
+    phases, note = {}, None
+    try:
+        jobs = [(cfg, sec * 0.25, sec * 0.35, 1000 + k) for k in range(cores_all)]
+        with ctx.Pool(cores_all) as pool:
+            res = pool.map_async(_cpu_env_worker, jobs).get(timeout=sec * 0.6 + 240)
+        env_only = sum(r['env_steps'] / r['t_env'] for r in res)
+        roll = sum(r['played'] / r['t_roll'] for r in res)
+        phases['env_only'] = {'cores': cores_all, 'whole_host': round(env_only, 1), 'per_core': round(env_only / cores_all, 1),
+                              'what': 'C oracle reset/step/observe, uniform random actions, %.0f s per process' % (sec * 0.25)}
+        phases['rollout'] = {'cores': cores_all, 'whole_host': round(roll, 1), 'per_core': round(roll / cores_all, 1),
+                             'what': 'env + %d Q-net forwards of batch 1 per step (Agents.choose_action, torch CPU 1 thread), no learn, '
+                                     '%.0f s per process' % (cfg['n_agents'], sec * 0.35)}
+    except Exception as e:  # noqa: BLE001  (the baseline must never take the bench line down)
+        note = 'whole-host phases failed: %s' % type(e).__name__
+    cores = max(1, min(5, cores_all))
+    jobs = [(cfg, sec * 0.4, 100 + k, collect_per_learn, learn_batch) for k in range(cores)]
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_worker, jobs)
-    env_only = sum(r['env_steps'] / r['t_env'] for r in res)
     full = sum(r['played'] / r['t_full'] for r in res)
-    return {'value': round(full, 1), 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port', 'cpu_model': _cpu_model(),
-            'per_core': round(full / cores, 1), 'env_only_value': round(env_only, 1), 'env_only_per_core': round(env_only / cores, 1),
-            'learns': int(sum(r['learns'] for r in res)),
-            'sample': '%d processes x %.0f s, one chip each: 15%% env-only (C oracle reset/step/observe, random actions), 85%% the '
-                      'reference loop shape (per step %d Q-net forwards of batch 1 via Agents.choose_action, torch CPU 1 thread; '
-                      'one VDN.learn of %d episodes per %d collected = the GPU run\'s %.2f sampled per collected episode)'
-                      % (cores, a.cpu_seconds, cfg['n_agents'], learn_batch, collect_per_learn, sampled_per_collected)}
+    learns = int(sum(r['learns'] for r in res))
+    learn_s_per_step = sum(r['learn_s'] for r in res) / max(1.0, sum(r['played'] for r in res))
+    phases['loop_with_learn'] = {'cores': cores, 'value': round(full, 1), 'per_core': round(full / cores, 1), 'learns': learns,
+                                 'learn_core_seconds_per_env_step': round(learn_s_per_step, 6),
+                                 'what': 'rollout + one VDN.learn of %d episodes per %d collected (= the GPU run\'s %.2f sampled per '
+                                         'collected episode), %.0f s per process' % (learn_batch, collect_per_learn, sampled_per_collected, sec * 0.4)}
+    out = {'value': round(full, 1), 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port', 'cpu_model': _cpu_model(),
+           'per_core': round(full / cores, 1), 'host_cores': cores_all, 'phases': phases,
+           'sample': '%d processes x %.0f s, one chip each, the reference loop shape: per step %d Q-net forwards of batch 1 via '
+                     'Agents.choose_action (torch CPU, 1 thread), env = C oracle, one VDN.learn of %d episodes per %d collected; '
+                     'env-only and rollout phases on all %d host cores (phases.*)'
+                     % (cores, sec * 0.4, cfg['n_agents'], learn_batch, collect_per_learn, cores_all)}
+    if 'rollout' in phases:
+        per_core_roll = phases['rollout']['per_core']
+        est = cores_all / (1.0 / max(per_core_roll, 1e-9) + learn_s_per_step)
+        out['env_only_value'] = phases['env_only']['whole_host']
+        out['env_only_per_core'] = phases['env_only']['per_core']
+        out['whole_host_loop_estimate'] = {'value': round(est, 1), 'cores': cores_all,
+                                           'how': 'cores / (1 / rollout per-core rate + learn core-seconds per env-step)'}
+    if note:
+        out['note'] = note
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -411,6 +543,7 @@ def main(argv=None):
                      **env.get_env_info())
     torch.manual_seed(1234 + rank)
     trainer = Trainer(env, args)
+    pol = trainer.agents.policy
 
     def one_step():
         if not a.eval_only:
@@ -422,12 +555,14 @@ def main(argv=None):
         one_step()
     torch.cuda.synchronize()
     if dist:
+        pol.allreduce_events = []  # every gradient all-reduce of the timed region is bracketed by a HIP event pair
         torch.distributed.barrier()
     t0 = time.perf_counter()
     played = 0
     for _ in range(a.steps):
         played += one_step()
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0  # this rank's own time, before it waits for the slowest one
     if dist:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
@@ -441,8 +576,18 @@ def main(argv=None):
         c = torch.ones(1, dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         torch.distributed.all_reduce(c, op=torch.distributed.ReduceOp.SUM)
         played_all, dt_max, joined = float(p.item()), float(m.item()), int(c.item())
+        # per-rank record (diagnosis of a sub-linear scaling curve): own round time, env steps played, mean all-reduce time
+        ev = pol.allreduce_events or []
+        ar_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / max(1, len(ev))
+        pol.allreduce_events = None
+        mine = torch.tensor([dt_own / a.steps * 1e3, float(played), ar_ms, float(len(ev))], dtype=torch.float64,
+                            device=device if backend == 'nccl' else 'cpu')
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        per_rank = [[float(v) for v in t.tolist()] for t in every]
     else:
         played_all, dt_max, joined = float(played), dt, 1
+        per_rank = None
 
     if rank != 0:
         if dist:
@@ -465,6 +610,19 @@ def main(argv=None):
             'parallelism': 'dp%d: chips sharded per rank, one flat RCCL all-reduce per learn' % world,
             'env_steps_per_round': round(played_all / a.steps, 1)},
     }
+    from marl_dmfb_amd.common import gemm_tuning
+    out['gemm_solutions'] = gemm_tuning.mode()
+    if per_rank is not None:
+        ms = [r[0] for r in per_rank]
+        ar = [r[2] for r in per_rank]
+        out['ranks'] = {'ms_per_step': [round(v, 3) for v in ms], 'ms_per_step_min': round(min(ms), 3), 'ms_per_step_max': round(max(ms), 3),
+                        'played': [int(r[1]) for r in per_rank],
+                        'allreduce_ms_per_learn': [round(v, 4) for v in ar], 'allreduce_ms_per_learn_max': round(max(ar), 4),
+                        'allreduces_timed_per_rank': int(per_rank[0][3]),
+                        'what': 'ms_per_step: each rank\'s own time per round before the closing barrier; allreduce_ms_per_learn: HIP event '
+                                'pair on the compute stream around the flat gradient all-reduce (the next learn\'s replay sample is queued '
+                                'inside that bracket and overlaps the collective)'}
+
     tiers = {}
     if meda:  # roofline of the MEDA observation kernel, timed like k_observe<n>: dispatch time stamps inside a lock-step loop
         roof_E = min(a.roofline_envs, 65536)
@@ -507,27 +665,49 @@ def main(argv=None):
         tiers.update(loop_breakdown(trainer, max(2, min(a.steps, 6))))
         tiers['env_policy_learn'] = {'env_steps_per_s': out['value'], 'what': out['config']['round']}
         tiers['in_loop_step_kernel'] = in_loop_step_kernel(trainer, env, n, fov)
+    if rank == 0 and not a.eval_only and fov == 9:
+        net = trainer.agents.policy.eval_rnn
+        if hasattr(net, '_hip_conv_ok'):
+            rl = conv_front_roofline(net, n, fov, [a.n_envs * n, a.batch_size * env.max_step * n], device)
+            if rl:
+                out['roofline_loop'] = rl
     trainer = None
     env.close()
     torch.cuda.empty_cache()
     if True:  # every N: rank 0 times the roofline kernel on its own GPU after the timed region
-        # the roofline kernel: FOV gather at a batch where the launch runs >= 50 us (SURVEY 8(d) launch-latency caveat)
-        big = env_only_tier(cfg, a.roofline_envs, 100, device, fov_kernel=True)
+        # the roofline kernel: FOV gather at a batch whose OUTPUT is 2.5x the 256 MiB Infinity Cache (655 360 chips x 980 B =
+        # 642 MB), so that `achieved` is an HBM figure; FETCH/WRITE_SIZE (`traffic`) cannot tell the Infinity Cache from HBM
+        # (MI355X_MICROARCH.md, HBM), the batch size can.  The cache-assisted 262 144-chip launch (257 MB) is kept as a tier.
+        big = env_only_tier(cfg, a.roofline_envs, 60, device, fov_kernel=True)
         fk = big['fov_kernel']
-        traffic = None
+        tj = {}
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get('k_observe_%dx%d_%dd_E%d' % (a.width, a.length, n, a.roofline_envs))
+                tj = json.load(open(tpath))
             except Exception:
-                traffic = None
+                tj = {}
+        traffic = tj.get('k_observe_%dx%d_%dd_E%d' % (a.width, a.length, n, a.roofline_envs))
+        out_bytes = a.roofline_envs * n * (3 * fov * fov + 2)
         out['roofline'] = {'bound': 'hbm', 'kernel': fk['kernel'], 'achieved': fk['algo_GBps'], 'peak': HBM_PEAK_GBPS,
                            'unit': 'GB/s', 'frac': fk['frac'], 'traffic': traffic, 'envs_per_launch': a.roofline_envs,
                            'algo_bytes_per_env': fk['algo_bytes_per_env'], 'avg_launch_us': fk['us_per_launch'],
                            'launches_timed': fk['launches_timed'],
                            'back_to_back_avg_launch_us': fk['back_to_back_us_per_launch'],
+                           'output_bytes_per_launch': out_bytes, 'output_over_infinity_cache': round(out_bytes / float(256 << 20), 2),
                            'timing': 'HIP event pair per launch carrying the dispatch start/end time stamps, %d launches, %s; nothing '
                                      'subtracted' % (fk['launches_timed'], fk['where'])}
+        if a.roofline_envs_cached and a.roofline_envs_cached != a.roofline_envs:
+            small = env_only_tier(cfg, a.roofline_envs_cached, 100, device, fov_kernel=True)
+            sk = small['fov_kernel']
+            tiers['fov_kernel_cache_resident'] = {
+                'kernel': sk['kernel'], 'envs_per_launch': a.roofline_envs_cached, 'avg_launch_us': sk['us_per_launch'],
+                'algo_GBps': sk['algo_GBps'], 'frac': sk['frac'], 'back_to_back_avg_launch_us': sk['back_to_back_us_per_launch'],
+                'traffic': tj.get('k_observe_%dx%d_%dd_E%d' % (a.width, a.length, n, a.roofline_envs_cached)),
+                'note': 'cache-assisted: %.0f MB of output against the 256 MiB Infinity Cache; not an HBM figure'
+                        % (a.roofline_envs_cached * n * (3 * fov * fov + 2) / 1e6)}
+            if not a.no_tiers and world == 1:
+                tiers['env_only_cache_resident_batch'] = {k: v for k, v in small.items() if k != 'fov_kernel'}
         if not a.no_tiers and world == 1:
             tiers['env_only_large_batch'] = big
             tiers['env_only_%d' % a.n_envs] = env_only_tier(cfg, a.n_envs, 300, device)

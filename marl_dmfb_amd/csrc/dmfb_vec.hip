@@ -172,6 +172,7 @@ struct dmfb_vec {
     int8_t *zoom_dev = nullptr;
     unsigned long long *band_dev = nullptr;  // DevPtrs::band
     int *dflags_dev = nullptr;               // DevPtrs::dflags
+    int obs_per_cu = 0;                      // cap on k_observe's persistent workgroups per CU (0: as many as LDS admits)
     size_t bytes = 0;
     int T_fused = 16;    // chips per workgroup of the fused step+observe launch (<= 64)
     int T_obs = 16;      // chips per workgroup of k_observe
@@ -217,6 +218,7 @@ template <int N> int observe_n(const dmfb_vec *h, const uint8_t *mask, int8_t *o
     // persistent grid: as many workgroups as fit the chip at once (LDS-limited, at most 8 per CU), or one per tile
     int per_cu = (int)((size_t)160 * 1024 / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    if (h->obs_per_cu > 0 && h->obs_per_cu < per_cu) per_cu = h->obs_per_cu;
     const int ntiles = (h->cfg.n_envs + T - 1) / T;
     const int grid = ntiles < h->n_cu * per_cu ? ntiles : h->n_cu * per_cu;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -424,6 +426,7 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
         if ((uint32_t)(((uint64_t)k * d.fov_magic) >> 32) != k / (uint32_t)d.fov) return fail(DMFB_ERR_UNSUPPORTED);
     h->split_min = 32768;
     if (const char *v = getenv("DMFB_VEC_SPLIT_MIN_ENVS")) h->split_min = atoi(v);  // tuning / test knob
+    if (const char *v = getenv("DMFB_VEC_OBS_PER_CU")) h->obs_per_cu = atoi(v);       // tuning knob: persistent workgroups per CU of k_observe
     rc = launch_reset(h, nullptr, 3, s);
     if (rc) return fail(rc);
     // the zoom table upload reads host memory owned by the handle: make it safe to use right away

@@ -90,8 +90,6 @@ class _TDLoss(torch.autograd.Function):
 
 class VDN:
     def __init__(self, args):
-        from ..common import gemm_tuning
-        gemm_tuning.enable()  # before the first GEMM: shipped rocBLAS / hipBLASLt solution choices (no on-line tuning)
         self.args = args
         self.n_actions = args.n_actions
         self.n_agents = args.n_agents
@@ -114,6 +112,9 @@ class VDN:
             self.device = torch.device(args.device)
         else:
             self.device = torch.device('cuda', torch.cuda.current_device()) if args.cuda else torch.device('cpu')
+        if self.device.type == 'cuda':  # (a CPU learner -- tests, bench.py's cpu_baseline workers -- never touches the GPU runtime)
+            from ..common import gemm_tuning
+            gemm_tuning.enable()  # before the first GEMM: shipped rocBLAS / hipBLASLt solution choices (no on-line tuning)
         for m in (self.eval_rnn, self.target_rnn, self.eval_vdn_net, self.target_vdn_net):
             m.to(self.device)
 
@@ -158,6 +159,8 @@ class VDN:
         # round): float32 tensor set before learn(); the next gradient all-reduce carries it and leaves the sums here
         self.ride_along = None
         self.ride_along_sum = None
+        self.overlap_hook = None       # callable queued while the next gradient all-reduce is in flight (one shot)
+        self.allreduce_events = None   # list -> (start, end) HIP event pair of every gradient all-reduce (diagnostics)
         self.dist = bool(getattr(args, 'dist', False)) and torch.distributed.is_available() \
             and torch.distributed.is_initialized() \
             and (torch.distributed.get_world_size() > 1 or bool(getattr(args, 'force_dist', False)))
@@ -181,28 +184,48 @@ class VDN:
             off += p.numel()
         self.target_rnn.load_state_dict(self.eval_rnn.state_dict())
 
-    def all_reduce_sum(self, flat):
-        """In-place SUM all-reduce of a flat tensor; returns it."""
-        if flat.is_cuda and torch.distributed.get_backend() == 'gloo':
+    def all_reduce_sum(self, flat, overlap=None):
+        """In-place SUM all-reduce of a flat tensor; returns it.  The collective is started asynchronously (RCCL runs it on its
+        own stream behind the work already queued on this one), `overlap()` -- work that does not depend on the result -- is
+        queued meanwhile, then this stream waits for the collective (no host block with RCCL)."""
+        dist = torch.distributed
+        if flat.is_cuda and dist.get_backend() == 'gloo':
             # rehearsal only (several ranks sharing one GPU over gloo): stage through the host
             host = flat.cpu()
-            torch.distributed.all_reduce(host, op=torch.distributed.ReduceOp.SUM)
+            work = dist.all_reduce(host, op=dist.ReduceOp.SUM, async_op=True)
+            if overlap is not None:
+                overlap()
+            work.wait()
             flat.copy_(host)
         else:
-            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            if overlap is not None:
+                overlap()
+            work.wait()
         return flat
 
     def _allreduce_grads(self, mask_sum):
         """ONE collective per learn step: [all gradients of the un-normalised loss, mask count, ride-along scalars].
         Flatten = one concatenation, un-flatten = one scale + one multi-tensor copy, so a rank adds ~4 launches to the
-        all-reduce."""
+        all-reduce.  `overlap_hook` (set by the Trainer: the NEXT learn's replay sample, which does not depend on this learn)
+        is queued while the collective is in flight; with `allreduce_events` set to a list every collective is bracketed by a
+        HIP event pair on the compute stream (bench.py: allreduce_ms_per_learn)."""
         params = [p for p in self.eval_parameters if p.grad is not None]
         n = sum(p.numel() for p in params)
         parts = [p.grad.reshape(-1) for p in params] + [mask_sum.reshape(1).to(torch.float32)]
         extra = self.ride_along
         if extra is not None:
             parts.append(extra.reshape(-1).to(device=mask_sum.device, dtype=torch.float32))
-        flat = self.all_reduce_sum(torch.cat(parts))
+        flat = torch.cat(parts)
+        timed = self.allreduce_events is not None and flat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        hook, self.overlap_hook = self.overlap_hook, None
+        flat = self.all_reduce_sum(flat, hook)
+        if timed:
+            e1.record()
+            self.allreduce_events.append((e0, e1))
         if extra is not None:
             self.ride_along_sum = flat[n + 1:].clone()
             self.ride_along = None

@@ -53,9 +53,16 @@ class Trainer:
         if self.dist:  # this rank's count travels with the gradients of the first learn (two exactly representable floats)
             pol.ride_along = torch.stack([local // 4096, local % 4096]).to(torch.float32)
             pol.ride_along_sum = None
-        for _ in range(self.args.train_time):
-            mini_batch = self.buffer.sample(min(self.buffer.current_size, self.args.batch_size))
+        prefetched = []
+        k_batch = min(self.buffer.current_size, self.args.batch_size)
+        for k in range(self.args.train_time):
+            mini_batch = prefetched.pop() if prefetched else self.buffer.sample(k_batch)
+            if self.dist and k + 1 < self.args.train_time and getattr(self.args, 'prefetch_sample', True):
+                # the next learn's sample does not depend on this learn: it is drawn (same generator, same order) while this
+                # learn's gradient all-reduce is in flight instead of after the optimizer step
+                pol.overlap_hook = lambda: prefetched.append(self.buffer.sample(k_batch))
             self.agents.train(mini_batch, self.trained_times)
+            pol.overlap_hook = None
             self.trained_times += 1
         if self.dist:
             if pol.ride_along_sum is None:  # no learn ran this round (train_time == 0): reduce the count by itself

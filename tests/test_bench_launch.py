@@ -45,10 +45,17 @@ def test_gpus_2_real_workload_on_one_card():
     """Two ranks share the card (gloo carries the collectives): the line must say n_gpus == 2 and the whole-job value
     must count both ranks' chips."""
     p = _run(['--gpus', '2', '--steps', '2', '--warmup', '1', '--n_envs', '512', '--batch_size', '64', '--train_time', '1',
-              '--buffer_size', '1024', '--roofline_envs', '16384'], BENCH_DIST_BACKEND='gloo')
+              '--buffer_size', '1024', '--roofline_envs', '16384', '--roofline_envs_cached', '0'], BENCH_DIST_BACKEND='gloo')
     assert p.returncode == 0, p.stderr[-3000:]
     rec = _json_line(p.stdout)
     assert rec['n_gpus'] == 2
     assert rec['config']['env_steps_per_round'] > 512 * 2  # both shards counted (>= 2 lock-steps per chip)
     assert rec['roofline']['kernel'] == 'dmfbk::k_observe<4>' and rec['roofline']['frac'] > 0
     assert 'cpu_baseline' not in rec
+    # a multi-rank line must be diagnosable from the record alone: per-rank round time, env steps, all-reduce time, GEMM mode
+    rk = rec['ranks']
+    assert len(rk['ms_per_step']) == len(rk['played']) == len(rk['allreduce_ms_per_learn']) == 2
+    assert rk['ms_per_step_min'] <= rk['ms_per_step_max'] <= rec['ms_per_step'] * 1.05
+    assert sum(rk['played']) == round(rec['config']['env_steps_per_round'] * rec['steps'])
+    assert rk['allreduces_timed_per_rank'] == 2 * 1 and min(rk['allreduce_ms_per_learn']) > 0     # steps x train_time
+    assert rec['gemm_solutions'].startswith(('tuned', 'library default', 'tuning to'))

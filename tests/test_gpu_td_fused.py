@@ -111,7 +111,9 @@ def test_action_outside_range_is_loud_not_out_of_bounds():
     assert int(bad.item()) == 2
     assert torch.isnan(num).item()
     g = q_e.grad.view(T, B, n, A)
-    assert torch.isnan(g[3, 2]).all() and torch.isnan(g[0, 5]).all()     # the two poisoned (step, episode) slots
+    # the two poisoned (step, episode) slots: NaN at every agent's taken action, and in the whole row of the offending agent
+    assert torch.isnan(g[3, 2]).any(dim=-1).all() and torch.isnan(g[0, 5]).any(dim=-1).all()
+    assert torch.isnan(g[3, 2, 1]).all() and torch.isnan(g[0, 5, 0]).all()
     ok = torch.ones(T, B, dtype=torch.bool, device='cuda')
     ok[3, 2] = ok[0, 5] = False
     assert torch.isfinite(g[ok]).all()

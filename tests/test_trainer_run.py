@@ -31,8 +31,9 @@ def _trainer(tmp, steps_per_round, dist=False, **over):
     from marl_dmfb_amd.train import Trainer
     env = types.SimpleNamespace(device=torch.device('cpu'), n_envs=6, seed=0, env_id0=0, obs_len=245, max_step=40,
                                 width=10, length=10)
+    over.setdefault('train_time', 2)
     args = make_args(cuda=False, device='cpu', dist=dist, n_actions=5, n_agents=4, obs_shape=(3, 9, 9, 2, 245), episode_limit=40,
-                     n_envs=6, batch_size=4, train_time=2, buffer_size=24, model_dir=os.path.join(tmp, 'model'),
+                     n_envs=6, batch_size=4, buffer_size=24, model_dir=os.path.join(tmp, 'model'),
                      result_dir=os.path.join(tmp, 'TrainResult'), evaluate_task=6, **over)
     torch.manual_seed(0)
     tr = Trainer(env, args)
@@ -151,3 +152,49 @@ def test_cli_defaults_perform_a_sane_number_of_learns():
     assert 10 <= a.n_steps // a.evaluate_cycle <= 40                     # 20 checkpoints, as n_steps=20 x evaluate_cycle=1e5
     b = get_train_args(['dmfb', '--step_scale', '1', '--batch_size', '128', '--train_time', '1'])
     assert (b.n_steps, b.anneal_steps, b.evaluate_cycle, b.batch_size, b.train_time) == (2000000, 150000, 100000, 128, 1)
+
+
+def _solo_rank(_index, port, tmp, prefetch):
+    """world size 1 over gloo with force_dist: the collective path (flat all-reduce, next sample drawn while it is in flight)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.distributed.init_process_group('gloo', rank=0, world_size=1)
+    tr = _trainer(os.path.join(tmp, 'p%d' % prefetch), 120, dist=True, force_dist=True, n_steps=600, evaluate_cycle=10 ** 9, train_time=3,
+                  prefetch_sample=bool(prefetch))
+    assert tr.dist
+    calls, state = [], {'in': False}
+    orig, pol = tr.buffer.sample, tr.agents.policy
+    orig_ar = pol.all_reduce_sum
+
+    def ar(flat, overlap=None):
+        state['in'] = True
+        try:
+            return orig_ar(flat, overlap)
+        finally:
+            state['in'] = False
+    pol.all_reduce_sum = ar
+    tr.buffer.sample = lambda k: (calls.append(state['in']) or orig(k))   # was the sample drawn while a collective was in flight?
+    tr.agents.policy.allreduce_events = []     # CPU tensors: stays empty, must not break anything
+    tr.run(online_evaluate=True)
+    torch.save({'sd': tr.agents.policy.eval_rnn.state_dict(), 'calls': calls, 'trained': tr.trained_times}, os.path.join(tmp, 'solo%d.pt' % prefetch))
+    torch.distributed.destroy_process_group()
+
+
+def test_prefetched_sample_changes_nothing(tmp_path):
+    """Data-parallel rounds draw the NEXT learn's replay sample while the gradient all-reduce is in flight (train.py:
+    collect_and_learn + VDN.overlap_hook).  Same generator, same order: the weights after 5 rounds x 3 learns are bit-identical
+    to those of the same loop with the prefetch switched off."""
+    tmp = str(tmp_path)
+    got = []
+    for prefetch in (1, 0):
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_solo_rank, args=(port, tmp, prefetch), nprocs=1, join=True)
+        got.append(torch.load(os.path.join(tmp, 'solo%d.pt' % prefetch)))
+    assert got[0]['trained'] == got[1]['trained'] == 15
+    # per round with the prefetch: sample 0 is drawn by the loop (hook not armed yet), samples 1 and 2 from inside the all-reduce
+    # (the one-shot hook already consumed); without: the hook is never armed
+    assert got[0]['calls'] == [False, True, True] * 5 and got[1]['calls'] == [False] * 15
+    for k, v in got[1]['sd'].items():
+        assert torch.equal(got[0]['sd'][k], v), k
