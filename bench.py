@@ -76,6 +76,8 @@ def parse(argv=None):
                     help='chips per launch of the roofline kernel: 655 360 x 980 B = 642 MB of output, 2.5x the 256 MiB Infinity Cache')
     ap.add_argument('--roofline_envs_cached', type=int, default=262144,
                     help='second, cache-assisted batch (257 MB of output) reported as tiers.fov_kernel_cache_resident')
+    ap.add_argument('--trained_tier_rounds', type=int, default=300,
+                    help='rounds of training before the env+policy tier with a trained policy is measured (0: skip that tier)')
     ap.add_argument('--launch_check', action='store_true',
                     help='rendezvous + collectives only (no GPU work): checks the --gpus N launch plumbing')
     return ap.parse_args(argv)
@@ -227,11 +229,57 @@ def in_loop_step_kernel(trainer, env, n, fov):
     ev = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in pairs)
     raw = sum(us) / max(1, len(us))
     b = algo_bytes_per_env_step(n, fov, degrade=env.has_maps)
-    return {'kernel': 'dmfbk::k_step<%d,%s>' % (n, 'true' if env.has_maps else 'false'), 'n_envs': env.n_envs, 'launches_timed': len(us),
+    return {'kernel': 'dmfbk::k_step<%d,%s,true>' % (n, 'true' if env.has_maps else 'false'), 'n_envs': env.n_envs, 'launches_timed': len(us),
             'event_pair_raw_us': round(raw, 2), 'empty_event_pair_us': round(ev[len(ev) // 2], 2),
             'algo_bytes_per_env_step': b, 'algo_GBps_raw': round(env.n_envs * b / raw / 1e3, 1),
             'frac_raw': round(env.n_envs * b / raw / 1e3 / HBM_PEAK_GBPS, 4),
             'note': 'launch-latency bound at this batch (SURVEY 8(d) caveat); nothing subtracted'}
+
+
+def trained_policy_tier(cfg, a, device, rounds):
+    """env+policy tier with a policy that actually finishes episodes: train a fresh learner for `rounds` rounds (the loop of
+    tools/train_sanity.py: 4 learns x 256 episodes per round, epsilon annealed over the first 60 %), then time rollouts only -- with
+    the finished chips kept out of the Q-network's conv front end and GRU-head kernel (the default, Evaluator.compact_every) and with
+    every row riding along to the slowest chip (compact_every = 0).  The headline runs a random-init policy whose episodes all
+    last the full 40 lock-steps, which is the best case for a lock-step batch; this is the other end."""
+    from marl_dmfb_amd.common.arguments import make_args
+    from marl_dmfb_amd.env.dmfb import VecDMFB
+    from marl_dmfb_amd.train import Trainer
+    E = a.n_envs
+    env = VecDMFB(n_envs=E, seed=7, device=device, **cfg)
+    info = env.get_env_info()
+    args = make_args(device=str(device), n_envs=E, batch_size=256, train_time=4, buffer_size=8 * E,
+                     anneal_steps=E * info['episode_limit'] * rounds * 0.6, use_graph=a.graph, **info)
+    torch.manual_seed(0)
+    tr = Trainer(env, args)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        tr.collect_and_learn()
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t0
+    w = tr.rolloutWorker
+    out = {'trained_rounds': rounds, 'train_seconds': round(t_train, 2), 'epsilon': round(float(w.epsilon), 4),
+           'what': 'rollouts only (epsilon-greedy at the trained epsilon, episodes recorded), policy trained for %d rounds of %d chips' % (rounds, E)}
+    for name, every in (('skipping_finished_chips', w.compact_every or 4), ('all_rows_every_step', 0)):
+        w.compact_every = every
+        w._graphs = {}
+        for _ in range(2):
+            w.generate_episode()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        played, n_ep, succ = 0, 0, 0.0
+        reps = 6
+        for _ in range(reps):
+            _, steps, _, success, ep = w.generate_episode()
+            played += int((~ep['padded']).sum().item())
+            succ += float((success > 0).float().mean().item())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {'env_steps_per_s': round(played / dt, 1), 'rollout_ms': round(dt / reps * 1e3, 3),
+                     'mean_steps_per_episode': round(played / (reps * E), 2), 'success_rate': round(succ / reps, 3)}
+    env.close()
+    return out
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, f32 operands (the reference's arithmetic type)
@@ -711,6 +759,8 @@ def main(argv=None):
         if not a.no_tiers and world == 1:
             tiers['env_only_large_batch'] = big
             tiers['env_only_%d' % a.n_envs] = env_only_tier(cfg, a.n_envs, 300, device)
+            if a.trained_tier_rounds > 0 and not a.degrade and fov == 9:
+                tiers['env_policy_trained'] = trained_policy_tier(cfg, a, device, a.trained_tier_rounds)
     if tiers:
         out['tiers'] = tiers
     if not a.no_cpu_baseline and world == 1 and not a.eval_only:

@@ -42,6 +42,17 @@ int crnn_conv9_forward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, co
 int crnn_front9_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
                         const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
                         const float *d_mlp_b, int od, float *d_out, int64_t out_stride, int out_cols, void *stream);
+/* The same for the LIVE chips of a lock-step rollout only (common/rollout.py: a chip whose episode is over is frozen until the
+ * round ends; the reference simply leaves its loop, rollout.py:108).  d_live_chips int32[<= rows / rows_per_chip]: ascending ids
+ * of the chips still playing, *d_n_live their count (both on the device: rollout_compact_alive of rollout_ops.h writes them, so a
+ * captured HIP graph follows the count without host involvement).  Input row of compact row k * rows_per_chip + a is
+ * d_live_chips[k] * rows_per_chip + a (obs and one-hot alike); d_out rows are COMPACT: row k * rows_per_chip + a.  `rows` =
+ * the worst case (all chips live) the grid is sized for; workgroups beyond the live rows exit at once; rows of d_out beyond
+ * *d_n_live * rows_per_chip are not written. */
+int crnn_front9_forward_live(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
+                             const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
+                             const float *d_mlp_b, int od, float *d_out, int64_t out_stride, int out_cols, const int32_t *d_live_chips,
+                             const int32_t *d_n_live, int rows_per_chip, void *stream);
 /* od*25+10 rounded up to a multiple of 64 (640 / 832), or CRNN_ERR_UNSUPPORTED. */
 int crnn_front_padded_cols(int od);
 /* The same front end for fov 19 (the MEDA v0_2 observation): conv_str(19) of network/base_net.py:23-33 =

@@ -46,6 +46,22 @@ int rollout_gru_head_select(const float *d_igates, const float *d_hgates, const 
                             int32_t *d_actions, int8_t *d_last_onehot, int8_t *d_ep_u, int8_t *d_ep_onehot, int32_t episode_limit,
                             int32_t t, float *d_q, void *stream);
 
+/* The chips still playing: d_live_chips int32[n_envs] receives the ids e with d_alive[e] != 0 in ASCENDING order, *d_n_live
+ * their number (device memory: the next lock-step's kernels read both there, so a captured HIP graph of the episode follows
+ * the shrinking batch without host involvement).  The reference's loop simply ends when an episode is over (rollout.py:108);
+ * in the lock-step batch a finished chip would otherwise ride through the Q-network until the slowest chip is done. */
+int rollout_compact_alive(int32_t n_envs, const uint8_t *d_alive, int32_t *d_live_chips, int32_t *d_n_live, void *stream);
+
+/* rollout_gru_head_select for the chips listed by rollout_compact_alive only: row k * n_agents + a of d_igates (COMPACT, as
+ * crnn_front9_forward_live of crnn_ops.h leaves the x-side operand) belongs to row d_live_chips[k] * n_agents + a of every other
+ * tensor (d_hgates, d_h, d_actions, d_last_onehot, the episode tensors, d_q: all in chip order).  Rows of finished chips are not
+ * touched; the Philox draw of a row is keyed by its chip-order index, so the picks do not depend on who else is still playing. */
+int rollout_gru_head_select_live(const float *d_igates, const float *d_hgates, const float *d_b_ih, const float *d_b_hh, float *d_h,
+                                 const float *d_fc_w, const float *d_fc_b, int32_t n_envs, int32_t n_agents, int32_t hidden,
+                                 int32_t n_actions, const float *d_epsilon, int32_t evaluate, uint64_t seed, const uint32_t *d_draw,
+                                 int32_t *d_actions, int8_t *d_last_onehot, int8_t *d_ep_u, int8_t *d_ep_onehot, int32_t episode_limit,
+                                 int32_t t, float *d_q, const int32_t *d_live_chips, const int32_t *d_n_live, void *stream);
+
 /* After the transition of lock-step t (rollout.py:118-129) for every chip e, with a = d_alive[e] BEFORE the step:
  *   r[e][t] = team_reward[e]; padded[e][t] = !a; terminated[e][t] = term[e]       (episode pointers may be NULL)
  *   sum_reward[e] += team_reward[e]; sum_constraints[e] += constraints[e]; sum_success[e] += success[e];

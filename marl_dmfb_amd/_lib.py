@@ -149,6 +149,7 @@ def crnn_ops():
     vp, i64 = C.c_void_p, C.c_int64
     lib.crnn_conv9_forward.argtypes = [vp, i64, i64, vp, vp, vp, vp, C.c_int, vp, i64, vp]
     lib.crnn_front9_forward.argtypes = [vp, i64, vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, i64, C.c_int, vp]
+    lib.crnn_front9_forward_live.argtypes = [vp, i64, vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, i64, C.c_int, vp, vp, C.c_int, vp]
     lib.crnn_front19_forward.argtypes = [vp, i64, vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, i64, C.c_int, vp]
     lib.crnn_front_padded_cols.argtypes = [C.c_int]
     lib.crnn_conv9_backward_parts.argtypes = [C.c_int]
@@ -171,6 +172,8 @@ def rollout_ops():
     vp, i32, u32, u64, f32 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_float
     lib.rollout_select_actions.argtypes = [vp, i32, i32, i32, vp, i32, u64, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.rollout_gru_head_select.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, u64, vp, vp, vp, vp, vp, i32, i32, vp, vp]
+    lib.rollout_gru_head_select_live.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, u64, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.rollout_compact_alive.argtypes = [i32, vp, vp, vp, vp]
     lib.rollout_post_step.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp]
     lib.rollout_last_hip_error.argtypes = []
     lib._typed = True

@@ -37,6 +37,12 @@ class Evaluator:
         self._graphs = {}
         self._rollout_lib = None
         self.fuse_tail = True  # GRU gate math + fc1 + epsilon-greedy as one kernel when the Q-net is the fov-9 CRNN
+        # Finished chips stay out of the Q-network: every `compact_every` lock-steps the ids of the chips still playing are
+        # listed on the device (include/rollout_ops.h: rollout_compact_alive) and the conv front end and the GRU-head kernel
+        # walk that list (worst-case grids, device-side count: graph-capturable).  Between two compactions the list is a
+        # superset of the live chips, which is harmless: a finished chip's rows are computed and ignored, as without the list.
+        # The two GRU projections stay full-size library GEMMs.  0 switches it off.
+        self.compact_every = 4
         # key of the epsilon-greedy Philox stream: the env seed, shifted per shard so that ranks draw different numbers
         self.rng_seed = (int(getattr(env, 'seed', 0)) * 0x9E3779B97F4A7C15 + int(getattr(env, 'env_id0', 0)) + 0x600) & 0xFFFFFFFFFFFFFFFF
 
@@ -133,9 +139,27 @@ class Evaluator:
         t_played = 0
         # the GRU input projection runs against rnn.weight_ih zero-padded to K = 640 / 832: one in-place copy per episode
         w_ih_pad = net.refresh_padded() if fused_tail else None
+        live = (fused_tail and self.compact_every > 0 and hasattr(net, 'front_features_live') and net._hip_geometry() == 9
+                and last_action.dtype == torch.int8)
+        if live:
+            live_chips = torch.empty(E, dtype=torch.int32, device=dev)
+            n_live = torch.zeros(1, dtype=torch.int32, device=dev)
+            x_live = torch.zeros((E * n, net.padded_cols()), dtype=torch.float32, device=dev)  # compact rows; stale rows stay finite
+            if lib.rollout_compact_alive(E, vp(alive.data_ptr()), vp(live_chips.data_ptr()), vp(n_live.data_ptr()), stream) != 0:
+                raise RuntimeError('rollout_compact_alive failed (hip %d)' % lib.rollout_last_hip_error())
         for t in range(T):
             obs2, la2 = obs.reshape(E * n, -1), last_action.reshape(E * n, -1)
-            if fused_tail:
+            if live:
+                # the same, for the listed chips only: x and x W_ih^T in compact row order, everything else in chip order
+                net.front_features_live(obs2, la2, live_chips, n_live, n, x_live)
+                ig, hg = torch.matmul(x_live, w_ih_pad.t()), torch.matmul(hidden, net.rnn.weight_hh.t())
+                rc = lib.rollout_gru_head_select_live(vp(ig.data_ptr()), vp(hg.data_ptr()), vp(net.rnn.bias_ih.data_ptr()),
+                                                      vp(net.rnn.bias_hh.data_ptr()), vp(hidden.data_ptr()), vp(net.fc1.weight.data_ptr()),
+                                                      vp(net.fc1.bias.data_ptr()), E, n, hidden.shape[1], A, vp(eps.data_ptr()),
+                                                      int(bool(evaluate)), self.rng_seed, vp(self._draw.data_ptr()),
+                                                      vp(actions.data_ptr()), vp(last_action.data_ptr()), p_u, p_oh, T, t, null,
+                                                      vp(live_chips.data_ptr()), vp(n_live.data_ptr()), stream)
+            elif fused_tail:
                 # front end + the two GRU GEMMs, then gate math + fc1 + epsilon-greedy in one launch (h updated in place)
                 ig, hg = net.act_gates(obs2, la2, hidden, w_ih_pad)
                 rc = lib.rollout_gru_head_select(vp(ig.data_ptr()), vp(hg.data_ptr()), vp(net.rnn.bias_ih.data_ptr()),
@@ -164,6 +188,9 @@ class Evaluator:
                                        p_o, p_on, stream)
             if rc != 0:
                 raise RuntimeError('rollout_post_step failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
+            if live and (t + 1) % self.compact_every == 0 and t + 1 < T:
+                if lib.rollout_compact_alive(E, vp(alive.data_ptr()), vp(live_chips.data_ptr()), vp(n_live.data_ptr()), stream) != 0:
+                    raise RuntimeError('rollout_compact_alive failed (hip %d)' % lib.rollout_last_hip_error())
             t_played = t + 1
             if not self._capturing and (t + 1) % self.sync_every == 0 and int(self._n_alive[0].item()) == 0:
                 break

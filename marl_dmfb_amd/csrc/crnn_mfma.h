@@ -22,8 +22,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlockM = 512;
 
-template <int OD> struct GeoM {
-    static constexpr int RB = OD <= 24 ? 16 : 12;       // rows per iteration (LDS-bound)
+// RBV: rows per workgroup iteration.  0 = the largest block one workgroup per CU can hold (16 rows at od 24, 12 at od 32:
+// 139 / 134 KB of LDS); 8 rows (70 / 89 KB) lets TWO workgroups share a CU at od 24, so one's barriers, prologue gathers and
+// stream-out overlap the other's MFMA phases.
+template <int OD, int RBV = 0> struct GeoM {
+    static constexpr int RB = RBV ? RBV : (OD <= 24 ? 16 : 12);  // rows per iteration (LDS-bound)
     static constexpr int CS = 53;                        // conv1 activation stride per channel: odd, so the epilogue's
                                                          // 16 channel lanes fall on different banks
     static constexpr int ROW_A1 = OD * CS;
@@ -43,10 +46,10 @@ template <int OD> struct GeoM {
 
 // conv2 for NT (1 or 2) tiles of 16 output positions: gathers of channel quad cq + 1 are issued before the MFMAs of
 // quad cq (sched_barrier keeps that order), so an LDS read has a whole quad of MFMA issue time to land.
-template <int OD, int NT>
-__device__ __forceinline__ void conv2_tiles(const float *s_a1, float *s_out, const float (&bw2)[GeoM<OD>::NSTEP2], float bias2,
+template <int OD, int RBV, int NT>
+__device__ __forceinline__ void conv2_tiles(const float *s_a1, float *s_out, const float (&bw2)[GeoM<OD, RBV>::NSTEP2], float bias2,
                                             int t0, int t1, int j, int kq, int ch, bool chv) {
-    using G = GeoM<OD>;
+    using G = GeoM<OD, RBV>;
     const float *ap[NT];
     f32x4 acc[NT];
 #pragma unroll
@@ -90,14 +93,19 @@ __device__ __forceinline__ void conv2_tiles(const float *s_a1, float *s_out, con
     }
 }
 
-template <int OD>
-__global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict__ obs, long obs_stride, long rows,
+template <int OD, int RBV = 0>
+__global__ __launch_bounds__(kBlockM, RBV == 0 ? 2 : 4) void k_conv9_mfma(const int8_t *__restrict__ obs, long obs_stride, long rows,
                                                         const float *__restrict__ w1, const float *__restrict__ b1,
                                                         const float *__restrict__ w2, const float *__restrict__ b2,
                                                         float *__restrict__ out, long out_stride, int out_cols,
                                                         const int8_t *__restrict__ onehot, int n_actions,
-                                                        const float *__restrict__ mlp_w, const float *__restrict__ mlp_b) {
-    using G = GeoM<OD>;
+                                                        const float *__restrict__ mlp_w, const float *__restrict__ mlp_b,
+                                                        const int32_t *__restrict__ live_chips, const int32_t *__restrict__ n_live,
+                                                        int rows_per_chip) {
+    // live_chips != NULL (rollout with finished chips): only the rows of the *n_live chips listed in live_chips (rows_per_chip
+    // consecutive rows each) are processed; input row = live_chips[k] * rows_per_chip + a, OUTPUT row = k * rows_per_chip + a
+    // (compact).  `rows` is then the worst case the grid was sized for; the device-side count decides.
+    using G = GeoM<OD, RBV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *s_in = lds;                              // [RB][244]  float image of the pixel bytes
     float *s_a1 = s_in + G::RB * G::IN_STRIDE;      // [RB][OD][53] conv1 activations
@@ -139,8 +147,14 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
         s_out[rr * G::OUT_STRIDE + n_feat + k] = 0.0f;
     }
 
+    if (live_chips) rows = min(rows, (long)n_live[0] * rows_per_chip);
     const long n_blocks = (rows + G::RB - 1) / G::RB;
     const int nin = 2 + n_actions;
+    auto src_row = [&](long cr) -> long {  // compact row -> row of the input tensors
+        if (!live_chips) return cr;
+        const long k = cr / rows_per_chip;
+        return (long)live_chips[k] * rows_per_chip + (cr - k * rows_per_chip);
+    };
     // The bytes of block i+1 are fetched into registers while block i is in conv1 and parked in LDS once conv1 is
     // done with s_in: the HBM latency of the int8 rows never sits between two barriers.
     float pf[G::NPF], pfv = 0.0f;
@@ -150,14 +164,15 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
 #pragma unroll
         for (int u = 0; u < G::NPF; ++u) {
             const int i = tid + u * kBlockM, rr = i / 243, p = i - rr * 243;
-            pf[u] = (i < G::RB * 243 && rr < rvb) ? (float)obs[(r0 + rr) * obs_stride + p] : 0.0f;  // rows past the end: finite zeros
+            pf[u] = (i < G::RB * 243 && rr < rvb) ? (float)obs[src_row(r0 + rr) * obs_stride + p] : 0.0f;  // rows past the end: finite zeros
         }
         if (mlp_w && tid < G::RB * G::VEC) {
             const int rr = tid / G::VEC, k = tid - rr * G::VEC;
             pfv = 0.0f;
             if (rr < rvb) {
-                if (k < 2) pfv = (float)obs[(r0 + rr) * obs_stride + 243 + k];
-                else if (onehot && k < nin) pfv = (float)onehot[(r0 + rr) * n_actions + (k - 2)];
+                const long sr = src_row(r0 + rr);
+                if (k < 2) pfv = (float)obs[sr * obs_stride + 243 + k];
+                else if (onehot && k < nin) pfv = (float)onehot[sr * n_actions + (k - 2)];
             }
         }
     };
@@ -238,8 +253,8 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
 #ifndef CRNN_PROBE_SKIP_CONV2
         {
             int t = sub;
-            for (; t + 4 < G::T2; t += 8) conv2_tiles<OD, 2>(s_a1, s_out, bw2, bias2, t, t + 4, j, kq, ch, chv);
-            if (t < G::T2) conv2_tiles<OD, 1>(s_a1, s_out, bw2, bias2, t, t, j, kq, ch, chv);
+            for (; t + 4 < G::T2; t += 8) conv2_tiles<OD, RBV, 2>(s_a1, s_out, bw2, bias2, t, t + 4, j, kq, ch, chv);
+            if (t < G::T2) conv2_tiles<OD, RBV, 1>(s_a1, s_out, bw2, bias2, t, t, j, kq, ch, chv);
         }
 #endif
         if (mlp_w && tid < G::RB * 10) s_out[mr * G::OUT_STRIDE + OD * 25 + mc] = fmaxf(mv, 0.0f);

@@ -391,25 +391,52 @@ struct PerDeviceOnce {
     }
 };
 
-template <int OD>
-int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w2, const float *b2,
-           float *out, long out_stride, int out_cols, const int8_t *onehot, int n_actions, const float *mlp_w, const float *mlp_b, hipStream_t s) {
-    using GM = crnn_mfma::GeoM<OD>;
+constexpr int kConv9DefaultRB24 = 0;  // 0: 16 rows, one workgroup per CU; 8: two workgroups per CU (measured: DESIGN.md section 8)
+
+struct LiveRows { const int32_t *chips; const int32_t *n; int rows_per_chip; };
+
+template <int OD, int RBV>
+int launch_rb(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w2, const float *b2,
+              float *out, long out_stride, int out_cols, const int8_t *onehot, int n_actions, const float *mlp_w, const float *mlp_b, hipStream_t s,
+              LiveRows live = LiveRows{nullptr, nullptr, 1}) {
+    using GM = crnn_mfma::GeoM<OD, RBV>;
     const size_t lds = GM::LDS_FLOATS * sizeof(float);
     static PerDeviceOnce attr_set;
     if (attr_set.need()) {
-        hipError_t e = hipFuncSetAttribute((const void *)crnn_mfma::k_conv9_mfma<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)crnn_mfma::k_conv9_mfma<OD, RBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
         attr_set.mark();
     }
     const long n_blocks = (rows + GM::RB - 1) / GM::RB;
-    const int grid = (int)(n_blocks < 256 ? n_blocks : 256);  // persistent: one workgroup per CU keeps the weights resident
+    // persistent: as many workgroups as the CUs hold at once (LDS-limited: one at 16 / 12 rows, two at 8), weights stay in registers
+    const long resident = 256L * (long)((size_t)160 * 1024 / lds);
+    const int grid = (int)(n_blocks < resident ? n_blocks : resident);
     (void)hipGetLastError();
-    hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, s, obs, obs_stride, rows, w1, b1, w2, b2,
-                       out, out_stride, out_cols, onehot, n_actions, mlp_w, mlp_b);
+    hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD, RBV>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, s, obs, obs_stride, rows, w1, b1, w2, b2,
+                       out, out_stride, out_cols, onehot, n_actions, mlp_w, mlp_b, live.chips, live.n, live.rows_per_chip);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
     return CRNN_OK;
+}
+
+// rows per workgroup iteration: CRNN_CONV9_RB=8|16 (tuning knob); default see conv9_rows_per_block
+static int conv9_rows_per_block(int od) {
+    static int knob = -1;
+    if (knob < 0) { const char *v = getenv("CRNN_CONV9_RB"); knob = v ? atoi(v) : 0; }
+    if (knob == 8 && od == 24) return 8;
+    if (knob == 16 || knob == 12) return 0;
+    return od == 24 ? kConv9DefaultRB24 : 0;
+}
+
+template <int OD>
+int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w2, const float *b2,
+           float *out, long out_stride, int out_cols, const int8_t *onehot, int n_actions, const float *mlp_w, const float *mlp_b, hipStream_t s,
+           LiveRows live = LiveRows{nullptr, nullptr, 1}) {
+    if constexpr (OD == 24) {
+        if (conv9_rows_per_block(OD) == 8)
+            return launch_rb<OD, 8>(obs, obs_stride, rows, w1, b1, w2, b2, out, out_stride, out_cols, onehot, n_actions, mlp_w, mlp_b, s, live);
+    }
+    return launch_rb<OD, 0>(obs, obs_stride, rows, w1, b1, w2, b2, out, out_stride, out_cols, onehot, n_actions, mlp_w, mlp_b, s, live);
 }
 
 template <int OD>
@@ -480,6 +507,22 @@ int crnn_front9_forward(const int8_t *d_obs, int64_t obs_stride, const int8_t *d
     if (rows == 0) return CRNN_OK;
     if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, out_cols, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
     return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, out_cols, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream);
+}
+
+int crnn_front9_forward_live(const int8_t *d_obs, int64_t obs_stride, const int8_t *d_onehot, int n_actions, int64_t rows,
+                             const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2, const float *d_mlp_w,
+                             const float *d_mlp_b, int od, float *d_out, int64_t out_stride, int out_cols, const int32_t *d_live_chips,
+                             const int32_t *d_n_live, int rows_per_chip, void *stream) {
+    if (!d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_mlp_w || !d_mlp_b || !d_out || rows < 0 || obs_stride < 245 ||
+        out_stride < od * 25 + 10 || n_actions < 0 || n_actions > 16 || !d_live_chips || !d_n_live || rows_per_chip < 1 ||
+        rows % rows_per_chip != 0)
+        return CRNN_ERR_BAD_ARG;
+    if (od != 24 && od != 32) return CRNN_ERR_UNSUPPORTED;
+    if (out_cols != 0 && (out_cols < od * 25 + 10 || out_cols > crnn_front_padded_cols(od) || out_cols > out_stride)) return CRNN_ERR_BAD_ARG;
+    if (rows == 0) return CRNN_OK;
+    const LiveRows live{d_live_chips, d_n_live, rows_per_chip};
+    if (od == 24) return launch<24>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, out_cols, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream, live);
+    return launch<32>(d_obs, obs_stride, rows, d_w1, d_b1, d_w2, d_b2, d_out, out_stride, out_cols, d_onehot, n_actions, d_mlp_w, d_mlp_b, (hipStream_t)stream, live);
 }
 
 int crnn_front_padded_cols(int od) { return od == 24 ? crnn_mfma::GeoM<24>::PAD_COLS : od == 32 ? crnn_mfma::GeoM<32>::PAD_COLS : CRNN_ERR_UNSUPPORTED; }

@@ -131,10 +131,9 @@ __device__ __forceinline__ void philox(uint32_t k0, uint32_t k1, uint32_t c0, ui
                                        uint32_t c3, uint32_t (&o)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;  // one v_mad_u64_u32 each
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
@@ -149,24 +148,26 @@ __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 
 // ---- per-lane env registers -------------------------------------------------------------------
+// Cells are kept packed, x | y << 16 (two int16 halves): the pair tests of the transition are packed 16-bit arithmetic, the
+// observation tile wants this very format, and a chip's cells take 2N registers instead of 4N.
 template <int N> struct EnvR {
-    int x[N], y[N], gx[N], gy[N];
+    uint32_t pos[N], goal[N];
     uint32_t step, flags, ulen, cum, rstep, rep, rmap;
 };
+__device__ __forceinline__ uint32_t xy16(uint32_t b) { return (b & 0xffu) | ((b & 0xff00u) << 8); }          // x | y<<8  -> x | y<<16
+__device__ __forceinline__ uint32_t xy8(uint32_t c) { return (c & 0xffu) | ((c >> 8) & 0xff00u); }            // x | y<<16 -> x | y<<8
+__device__ __forceinline__ int cell_x(uint32_t c) { return (int)(c & 0xffffu); }
+__device__ __forceinline__ int cell_y(uint32_t c) { return (int)(c >> 16); }
 
 template <int N>
 __device__ __forceinline__ void load_env(const DevPtrs &p, int E, int e, EnvR<N> &r) {
     using R = Rec<N>;
 #pragma unroll
     for (int w = 0; w < R::NP; ++w) {
-        uint32_t pw = p.st[(size_t)(R::W_POS + w) * E + e];
-        uint32_t gw = p.st[(size_t)(R::W_GOAL + w) * E + e];
-        r.x[2 * w] = pw & 0xff; r.y[2 * w] = (pw >> 8) & 0xff;
-        r.gx[2 * w] = gw & 0xff; r.gy[2 * w] = (gw >> 8) & 0xff;
-        if (2 * w + 1 < N) {
-            r.x[2 * w + 1] = (pw >> 16) & 0xff; r.y[2 * w + 1] = (pw >> 24) & 0xff;
-            r.gx[2 * w + 1] = (gw >> 16) & 0xff; r.gy[2 * w + 1] = (gw >> 24) & 0xff;
-        }
+        const uint32_t pw = p.st[(size_t)(R::W_POS + w) * E + e];
+        const uint32_t gw = p.st[(size_t)(R::W_GOAL + w) * E + e];
+        r.pos[2 * w] = xy16(pw); r.goal[2 * w] = xy16(gw);
+        if (2 * w + 1 < N) { r.pos[2 * w + 1] = xy16(pw >> 16); r.goal[2 * w + 1] = xy16(gw >> 16); }
     }
     uint32_t s = p.st[(size_t)R::W_STEP * E + e];
     r.step = s & 0xffff; r.flags = (s >> 16) & kFlagMask; r.ulen = s >> kUlenShift;
@@ -176,9 +177,10 @@ __device__ __forceinline__ void load_env(const DevPtrs &p, int E, int e, EnvR<N>
     r.rmap = p.st[(size_t)R::W_RMAP * E + e];
 }
 
-template <int N> __device__ __forceinline__ uint32_t pack_pos(const int (&x)[N], const int (&y)[N], int w) {
-    uint32_t v = (uint32_t)x[2 * w] | ((uint32_t)y[2 * w] << 8);
-    if (2 * w + 1 < N) v |= ((uint32_t)x[2 * w + 1] << 16) | ((uint32_t)y[2 * w + 1] << 24);
+// record word w of a packed-cell array: agent 2w in the low half, 2w+1 in the high half, each x | y << 8
+template <int N> __device__ __forceinline__ uint32_t pack_pos(const uint32_t (&cells)[N], int w) {
+    uint32_t v = xy8(cells[2 * w]);
+    if (2 * w + 1 < N) v |= xy8(cells[2 * w + 1]) << 16;
     return v;
 }
 
@@ -187,8 +189,8 @@ __device__ __forceinline__ void store_env(const DevPtrs &p, int E, int e, const 
     using R = Rec<N>;
 #pragma unroll
     for (int w = 0; w < R::NP; ++w) {
-        p.st[(size_t)(R::W_POS + w) * E + e] = pack_pos<N>(r.x, r.y, w);
-        if (with_goal) p.st[(size_t)(R::W_GOAL + w) * E + e] = pack_pos<N>(r.gx, r.gy, w);
+        p.st[(size_t)(R::W_POS + w) * E + e] = pack_pos<N>(r.pos, w);
+        if (with_goal) p.st[(size_t)(R::W_GOAL + w) * E + e] = pack_pos<N>(r.goal, w);
     }
     p.st[(size_t)R::W_STEP * E + e] = (r.step & 0xffff) | (r.flags << 16) | (r.ulen << kUlenShift);
     p.st[(size_t)R::W_CUM * E + e] = r.cum;
@@ -202,7 +204,7 @@ template <int N> __device__ __forceinline__ bool any_dup(const EnvR<N> &r) {
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int j = i + 1; j < N; ++j) d |= (r.x[i] == r.x[j]) & (r.y[i] == r.y[j]);
+        for (int j = i + 1; j < N; ++j) d |= r.pos[i] == r.pos[j];
     return d;
 }
 
@@ -247,15 +249,13 @@ __device__ __forceinline__ void gen_task_wave(const DevCfg &c, uint32_t env_gid,
     }
 }
 
-template <int N> __device__ __forceinline__ void task_to_env(const uint32_t (&pts)[N], EnvR<N> &r, int (&sx)[N], int (&sy)[N]) {
+// the accepted 2N points (point i = start of droplet i, point N + i = its goal, each x | y << 8) become the chip's cells
+template <int N> __device__ __forceinline__ void task_to_env(const uint32_t (&pts)[N], EnvR<N> &r) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint32_t s = (pts[i >> 1] >> (16 * (i & 1))) & 0xffff;
         const int gi = N + i;
-        const uint32_t g = (pts[gi >> 1] >> (16 * (gi & 1))) & 0xffff;
-        sx[i] = s & 0xff; sy[i] = s >> 8;
-        r.x[i] = sx[i]; r.y[i] = sy[i];
-        r.gx[i] = g & 0xff; r.gy[i] = g >> 8;
+        r.pos[i] = xy16((pts[i >> 1] >> (16 * (i & 1))) & 0xffff);
+        r.goal[i] = xy16((pts[gi >> 1] >> (16 * (gi & 1))) & 0xffff);
     }
 }
 
@@ -299,9 +299,9 @@ __device__ __forceinline__ uint32_t gen_blocks_wave(const DevCfg &c, uint32_t en
     return myblk;
 }
 
-template <int N> __device__ __forceinline__ void store_starts(const DevPtrs &p, int E, int e, const int (&sx)[N], const int (&sy)[N]) {
+template <int N> __device__ __forceinline__ void store_starts(const DevPtrs &p, int E, int e, const uint32_t (&cells)[N]) {
 #pragma unroll
-    for (int w = 0; w < Rec<N>::NP; ++w) p.starts[(size_t)w * E + e] = pack_pos<N>(sx, sy, w);
+    for (int w = 0; w < Rec<N>::NP; ++w) p.starts[(size_t)w * E + e] = pack_pos<N>(cells, w);
 }
 
 // ---- health maps ------------------------------------------------------------------------------
@@ -460,6 +460,10 @@ __device__ __forceinline__ uint32_t pk_clamp_i(uint32_t a, uint32_t lo, uint32_t
     s16x2 v = __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, lo));
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(v, __builtin_bit_cast(s16x2, hi)));
 }
+__device__ __forceinline__ uint32_t pk_abs(uint32_t a) {
+    const s16x2 v = __builtin_bit_cast(s16x2, a);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, -v));
+}
 __device__ __forceinline__ uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) * 0x10001u; }
 __device__ __forceinline__ uint32_t to_xy(uint32_t byte_pair) { return (byte_pair & 0xffu) | ((byte_pair & 0xff00u) << 8); }
 
@@ -606,11 +610,16 @@ struct StepArgs {
     dmfb_vec_step_out out;
 };
 
-template <int N, bool MAPS>
-__global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a) {
+// Minimum waves per SIMD the register allocator must leave room for: the transition is ONE generation of resident waves, so its
+// speed follows the occupancy.  n <= 10 fits 128 VGPRs (four waves) with at most 4 spilled registers; larger n would spill dozens.
+constexpr int step_min_waves(int n) { return n <= 10 ? 4 : 3; }
+// OBS: the launch also builds the observations (fused small-batch launch); false = step-only launch (a.out.d_obs is NULL), which
+// then carries none of the observation phases' code or registers
+template <int N, bool MAPS, bool OBS>
+__global__ __launch_bounds__(kBlock, step_min_waves(N)) void k_step(DevCfg c, DevPtrs p, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = c.T, E = c.E;
-    const bool want_obs = a.out.d_obs != nullptr;
+    constexpr bool want_obs = OBS;
     const int tid = threadIdx.x;
     const int tile_base = blockIdx.x * T;
     const int shift = want_obs ? (int)(((uintptr_t)a.out.d_obs + (size_t)tile_base * N * c.obs_len) & 15) : 0;
@@ -648,172 +657,170 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
             if (a.out.d_team_reward) a.out.d_team_reward[e] = 0.0;
         }
         if (active) {
-            // ---- everything the serial move loop needs is fetched up front (independent loads in flight
-            // together): actions, and - with maps - the health under every droplet and its draw.  A droplet's
-            // cell before ITS move does not depend on the other droplets' moves.
-            int acts[N];
+            // Register diet (this kernel is ONE generation of resident waves, so its speed is set by how many waves a SIMD
+            // holds): actions are packed 3 bits each, per-droplet booleans are bit masks, cells are packed int16 pairs, the
+            // draw and the health of a droplet are reduced to ONE bit ("it moves") as soon as both exist, and rewards are
+            // produced, stored and summed one at a time.
             const size_t a0 = (size_t)e * N;
-            if (a.flags & DMFB_ACT_I8) {
+            uint64_t apk = 0;  // actions: 0 STALL, 1..4 moves (dmfb.py:26-31); anything else = 5 (no move, not a STALL)
 #pragma unroll
-                for (int i = 0; i < N; ++i) acts[i] = ((const int8_t *)a.actions)[a0 + i];
-            } else if (a.flags & DMFB_ACT_I64) {
-#pragma unroll
-                for (int i = 0; i < N; ++i) acts[i] = (int)((const long long *)a.actions)[a0 + i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < N; ++i) acts[i] = ((const int32_t *)a.actions)[a0 + i];
+            for (int i = 0; i < N; ++i) {
+                const int v = (a.flags & DMFB_ACT_I8) ? (int)((const int8_t *)a.actions)[a0 + i]
+                            : (a.flags & DMFB_ACT_I64) ? (int)((const long long *)a.actions)[a0 + i] : ((const int32_t *)a.actions)[a0 + i];
+                apk |= (uint64_t)((unsigned)v > 4u ? 5u : (unsigned)v) << (3 * i);
             }
-            double prob[N], draw[N];
+            auto act_of = [&](int i) { return (int)((apk >> (3 * i)) & 7u); };
             const bool use_draws = MAPS || a.uniforms != nullptr;
             const bool compact = MAPS && p.dflags[0] != 0;
-            uint8_t kcnt[N];
-
+            uint32_t mvm = (1u << N) - 1u;  // bit i: droplet i's draw lets it move (u <= health, dmfb.py:335)
             if (use_draws) {
+                uint64_t kpk = 0;  // degrade counts under the droplets, 4 bits each: all the gathers are in flight together
+#ifndef DMFB_ABLATE_KMAP  // DMFB_ABLATE_*: timing experiments only (tools/build_variant.sh with EXTRA_FLAGS): wrong results
+                if (compact) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) kpk |= (uint64_t)kmap_get(p, kmap_bytes(cells), e, cell_x(r.pos[i]) * c.L + cell_y(r.pos[i])) << (4 * i);
+                }
+#endif
+                const uint32_t gen = c.b_degrade ? r.rmap - 1u : 0u;  // counter value the current maps were drawn with
+                mvm = 0;
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    prob[i] = 1.0;
-                    kcnt[i] = 0;
-                    // getMoveProb (dmfb.py:361-363): the float64 map, or one byte of the degrade-count map
-                    if (MAPS && !compact) prob[i] = p.health[(size_t)e * cells + r.x[i] * c.L + r.y[i]];
-#ifndef DMFB_ABLATE_KMAP  // DMFB_ABLATE_*: timing experiments only (tools/build_variant.sh with EXTRA_FLAGS): wrong results
-                    if (compact) kcnt[i] = (uint8_t)kmap_get(p, kmap_bytes(cells), e, r.x[i] * c.L + r.y[i]);
-#endif
-                    if (a.uniforms) draw[i] = a.uniforms[a0 + i];
-                }
-                if (!a.uniforms) {
-#pragma unroll
-                    for (int i = 0; i < N; ++i) {
+                    const int cell = cell_x(r.pos[i]) * c.L + cell_y(r.pos[i]);
+                    double prob = 1.0;  // getMoveProb (dmfb.py:361-363): the float64 map, or health rebuilt from the degrade count
+                    if (MAPS && !compact) prob = p.health[(size_t)e * cells + cell];
+                    if (compact) {  // health = 1.0 * degrade * ... * degrade (count times), degrade from the map's Philox stream
+                        const int k = (int)((kpk >> (4 * i)) & 15u);
+                        if (k == kCountMax) prob = p.health[(size_t)e * cells + cell];  // saturated count: the map itself
+                        else if (k != 0) prob = health_from_count(degrade_of(c, c.env_id0 + (uint32_t)e, gen, cell), k);
+                    }
+                    double draw;
+                    if (a.uniforms) draw = a.uniforms[a0 + i];
+                    else {
 #ifdef DMFB_ABLATE_PHILOX
-                        draw[i] = (double)((r.rstep * 2654435761u + (uint32_t)i * 40503u) >> 8) * (1.0 / 16777216.0);
+                        draw = (double)((r.rstep * 2654435761u + (uint32_t)i * 40503u) >> 8) * (1.0 / 16777216.0);
 #else
                         uint32_t w[4];
                         philox(c.k0, c.k1, c.env_id0 + (uint32_t)e, r.rstep, (uint32_t)i, STREAM_MOVE << 8, w);
-                        draw[i] = u53(w[0], w[1]);
+                        draw = u53(w[0], w[1]);
 #endif
                     }
-                }
-                if (compact) {  // health = 1.0 * degrade * ... * degrade (count times), degrade from the map's Philox stream
-                    const uint32_t gen = c.b_degrade ? r.rmap - 1u : 0u;  // counter value the current maps were drawn with
-#pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        const int cell = r.x[i] * c.L + r.y[i];
-                        if (kcnt[i] == kCountMax) prob[i] = p.health[(size_t)e * cells + cell];  // saturated count: the map itself
-                        else if (kcnt[i] != 0) prob[i] = health_from_count(degrade_of(c, c.env_id0 + (uint32_t)e, gen, cell), kcnt[i]);
-                    }
+                    mvm |= (uint32_t)(draw <= prob) << i;
                 }
             }
+            const uint32_t k_hi = (uint32_t)(c.W - 1) | ((uint32_t)(c.L - 1) << 16);
+            // Droplet.move (dmfb.py:103-124) of a packed cell: +-1 on one axis, clamped to the chip
+            auto moved = [&](uint32_t cell, int act) {
+                const uint32_t delta = act == 1 ? 0x00000001u : act == 2 ? 0x0000ffffu : act == 3 ? 0xffff0000u : act == 4 ? 0x00010000u : 0u;
+                return pk_clamp_i(pk_add(cell, delta), 0u, k_hi);
+            };
+            uint32_t (&P)[N] = r.pos;
+            const uint32_t (&Gp)[N] = r.goal;
             // _isTouchingBlocks (dmfb.py:301-308) of every droplet's TENTATIVE cell: it depends only on the
             // droplet's own position and action, so it is evaluated up front, one pass over the blocks.
-            bool blocked[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) blocked[i] = false;
+            uint32_t blocked = 0;
             if (c.nb > 0) {
-                int tx[N], ty[N];
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    int nx = r.x[i] + (acts[i] == 1) - (acts[i] == 2), ny = r.y[i] + (acts[i] == 4) - (acts[i] == 3);
-                    tx[i] = nx > c.W - 1 ? c.W - 1 : (nx < 0 ? 0 : nx);
-                    ty[i] = ny > c.L - 1 ? c.L - 1 : (ny < 0 ? 0 : ny);
-                }
                 for (int b = 0; b < c.nb; ++b) {
                     const uint32_t o = p.blocks[(size_t)b * E + e];
                     const int x0 = o & 0xff, x1 = (o >> 8) & 0xff, y0 = (o >> 16) & 0xff, y1 = o >> 24;
 #pragma unroll
-                    for (int i = 0; i < N; ++i) blocked[i] |= (tx[i] >= x0) & (tx[i] <= x1) & (ty[i] >= y0) & (ty[i] <= y1);
+                    for (int i = 0; i < N; ++i) {
+                        const uint32_t t = moved(P[i], act_of(i));
+                        const int tx = (int)(t & 0xffffu), ty = (int)(t >> 16);
+                        blocked |= (uint32_t)((tx >= x0) & (tx <= x1) & (ty >= y0) & (ty <= y1)) << i;
+                    }
                 }
             }
-            // ---- moveDroplets (dmfb.py:253-299)
-            int code[N], pastx[N], pasty[N], sta[N], dyn[N];
-            bool was_done[N];
+            // ---- moveDroplets (dmfb.py:253-299).  Packed int16 pairs (x | y << 16): one packed subtract, one packed unsigned
+            // min and ONE compare per pair test (v_pk_sub_i16 / v_pk_min_u16) instead of two of each plus a mask AND.
+            const uint32_t k_one = 0x00010001u, k_two = 0x00020002u;
+            auto pdist = [](uint32_t u, uint32_t v) {  // Manhattan distance of two packed cells
+                const uint32_t ad = pk_abs(pk_sub(u, v));
+                return (int)((ad & 0xffffu) + (ad >> 16));
+            };
+            // |ax - bx| <= 1 and |ay - by| <= 1, given a1 = a + (1, 1): both halves of a1 - b lie in {0, 1, 2}
+            auto near1p = [&](uint32_t a1, uint32_t bcell) {
+                const uint32_t t = pk_sub(a1, bcell);
+                return pk_min_u(t, k_two) == t;
+            };
+            uint32_t past[N];
+            uint32_t cpk = 0, wdm = 0;  // reward code of droplet i in bits 2i..2i+1; bit i: it was on its goal before the moves
             r.step += 1;
-#pragma unroll
-            for (int i = 0; i < N; ++i) was_done[i] = (iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) == 0;
             const bool dup = (r.flags & FLAG_DUP) != 0;
 #pragma unroll
             for (int i = 0; i < N; ++i) {  // moveOneDroplet (dmfb.py:325-359), strictly in index order
-                const int x0 = r.x[i], y0 = r.y[i];
-                const int old = iabs(x0 - r.gx[i]) + iabs(y0 - r.gy[i]);
-                pastx[i] = x0; pasty[i] = y0;
-                const int act = acts[i];
-                if (c.stall && old == 0) {
-                    code[i] = 0;
-                } else {
-                    const bool mv = use_draws ? (draw[i] <= prob[i]) : true;
-                    if (mv) {
-                        int nx = x0 + (act == 1) - (act == 2), ny = y0 + (act == 4) - (act == 3);  // Droplet.move (dmfb.py:103-124)
-                        nx = nx > c.W - 1 ? c.W - 1 : (nx < 0 ? 0 : nx);
-                        ny = ny > c.L - 1 ? c.L - 1 : (ny < 0 ? 0 : ny);
-                        if (blocked[i]) { nx = x0; ny = y0; }  // revert when touching a block (dmfb.py:338-340)
-                        r.x[i] = nx; r.y[i] = ny;
+                past[i] = P[i];
+                const int act = act_of(i);
+                const int old = pdist(P[i], Gp[i]);
+                wdm |= (uint32_t)(old == 0) << i;
+                int code = 0;
+                if (!(c.stall && old == 0)) {
+                    if ((mvm >> i) & 1u) {
+                        uint32_t np = moved(P[i], act);
+                        if ((blocked >> i) & 1u) np = P[i];  // revert when touching a block (dmfb.py:338-340)
                         bool clash = false;  // _isinvalidaction (dmfb.py:310-323)
-                        if (dup) clash = any_dup<N>(r);
-                        else {
+                        if (dup) {
+                            P[i] = np;
+#pragma unroll
+                            for (int u = 0; u < N; ++u)
+#pragma unroll
+                                for (int v = u + 1; v < N; ++v) clash |= P[u] == P[v];
+                        } else {
 #pragma unroll
                             for (int j = 0; j < N; ++j)
-                                if (j != i) clash |= (r.x[j] == nx) & (r.y[j] == ny);
+                                if (j != i) clash |= P[j] == np;
                         }
-                        if (clash) { r.x[i] = x0; r.y[i] = y0; }
+                        P[i] = clash ? past[i] : np;
                     }
-                    const int nd = iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i]);
-                    code[i] = (nd == old && old == 0) ? 1 : (nd == old && act == 0) ? 2 : (nd < old) ? 1 : 3;
+                    const int nd = pdist(P[i], Gp[i]);
+                    code = (nd == old && old == 0) ? 1 : (nd == old && act == 0) ? 2 : (nd < old) ? 1 : 3;
                 }
+                cpk |= (uint32_t)code << (2 * i);
             }
             r.rstep += 1;
+            int sta[N], dyn[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) { sta[i] = 0; dyn[i] = 0; }
 #pragma unroll
-            for (int i = 0; i < N; ++i)
+            for (int i = 0; i < N; ++i) {
+                const uint32_t c1 = pk_add(P[i], k_one), p1 = pk_add(past[i], k_one);
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     if (j > i) {  // comflic_static (dmfb.py:254-261)
-                        const bool near = (iabs(r.x[i] - r.x[j]) <= 1) & (iabs(r.y[i] - r.y[j]) <= 1);
+                        const bool near = near1p(c1, P[j]);
                         sta[i] += near; sta[j] += near;
                     }
                     if (j != i) {  // comflic_dynamic (dmfb.py:263-271)
-                        const bool near = (iabs(pastx[i] - r.x[j]) <= 1) & (iabs(pasty[i] - r.y[j]) <= 1);
+                        const bool near = near1p(p1, P[j]);
                         dyn[i] += near; dyn[j] += near;
                     }
                 }
+            }
             int constraints = 0;
             bool all_done = true;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 constraints += sta[i] + dyn[i];
-                all_done &= (iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) == 0;
-            }
-            // rewards: ((base - 2*sta) - 2*dy), 0 if it was done, +10, +10  (dmfb.py:288-296)
-            double rew[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const double base = code[i] == 0 ? 0.0 : code[i] == 1 ? -0.1 : code[i] == 2 ? -0.25 : -0.4;
-                double v = (base - (double)(2 * sta[i])) - (double)(2 * dyn[i]);
-                if (c.stall && was_done[i]) v = 0.0;
-                if (all_done) {
-                    v = v + 10.0;
-                    if (constraints == 0) v = v + 10.0;
-                }
-                rew[i] = v;
+                all_done &= P[i] == Gp[i];
             }
             bool log_full = false;
             if (MAPS && (a.flags & DMFB_STEP_RECORD)) {  // addUsage (dmfb.py:459-463): append this step to the chip's usage log
                 uint16_t *ul = p.ulog + ((size_t)e * c.ucap + r.ulen) * c.lstride;
 #ifndef DMFB_ABLATE_LOG
+                auto entry = [&](int i) { return P[i] != Gp[i] ? (uint32_t)(cell_x(P[i]) * c.L + cell_y(P[i])) : 0xffffu; };
                 if (c.lstride == 16) {  // one whole, aligned 32-byte sector per step: no partial-sector write reaches HBM
                     uint32_t w[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         uint32_t lo = 0xffffu, hi = 0xffffu;
-                        if (2 * k < N && (iabs(r.x[2 * k] - r.gx[2 * k]) + iabs(r.y[2 * k] - r.gy[2 * k])) != 0) lo = (uint32_t)(r.x[2 * k] * c.L + r.y[2 * k]);
-                        if (2 * k + 1 < N && (iabs(r.x[2 * k + 1] - r.gx[2 * k + 1]) + iabs(r.y[2 * k + 1] - r.gy[2 * k + 1])) != 0)
-                            hi = (uint32_t)(r.x[2 * k + 1] * c.L + r.y[2 * k + 1]);
+                        if (2 * k < N) lo = entry(2 * k);
+                        if (2 * k + 1 < N) hi = entry(2 * k + 1);
                         w[k] = lo | (hi << 16);
                     }
                     ((uint4 *)ul)[0] = make_uint4(w[0], w[1], w[2], w[3]);
                     ((uint4 *)ul)[1] = make_uint4(w[4], w[5], w[6], w[7]);
                 } else {
 #pragma unroll
-                    for (int i = 0; i < N; ++i)
-                        ul[i] = (iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) != 0 ? (uint16_t)(r.x[i] * c.L + r.y[i]) : (uint16_t)0xffff;
+                    for (int i = 0; i < N; ++i) ul[i] = (uint16_t)entry(i);
                 }
 #endif
                 r.ulen += 1;
@@ -822,38 +829,46 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
             r.cum += (uint32_t)constraints;
             const bool in_time = (int)r.step < c.max_step;  // DMFBenv.step (dmfb.py:577-585)
             const bool success = in_time && all_done && r.cum == 0;
-            bool term = true;
+            const bool term = in_time ? all_done : true;
+            // rewards: ((base - 2*sta) - 2*dy), 0 if it was done, +10, +10  (dmfb.py:288-296); produced one at a time
+            auto reward = [&](int i) {
+                const int code = (int)((cpk >> (2 * i)) & 3u);
+                const double base = code == 0 ? 0.0 : code == 1 ? -0.1 : code == 2 ? -0.25 : -0.4;
+                double v = (base - (double)(2 * sta[i])) - (double)(2 * dyn[i]);
+                if (c.stall && ((wdm >> i) & 1u)) v = 0.0;
+                if (all_done) {
+                    v = v + 10.0;
+                    if (constraints == 0) v = v + 10.0;
+                }
+                if (a.out.d_rewards) a.out.d_rewards[(size_t)e * N + i] = v;
+                if (a.out.d_dones) a.out.d_dones[(size_t)e * N + i] = (uint8_t)(in_time ? (P[i] == Gp[i]) : true);
+                return v;
+            };
+            double s;  // np.sum(list)/n in NumPy's order (rollout.py:33): sequential below 8 values, else 8 partial sums
+            if constexpr (N < 8) {
+                s = 0.0;
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const bool d = in_time ? ((iabs(r.x[i] - r.gx[i]) + iabs(r.y[i] - r.gy[i])) == 0) : true;
-                term &= d;
-                if (a.out.d_dones) a.out.d_dones[(size_t)e * N + i] = (uint8_t)d;
-                if (a.out.d_rewards) a.out.d_rewards[(size_t)e * N + i] = rew[i];
+                for (int i = 0; i < N; ++i) s = s + reward(i);
+            } else {
+                constexpr int M = N - (N % 8);
+                // q[j] = rew[j] + rew[j + 8] + ... (j < 8), then ((q0+q1)+(q2+q3))+((q4+q5)+(q6+q7)), then the rest in index order
+                auto q = [&](int j) {
+                    double v = reward(j);
+#pragma unroll
+                    for (int i = 8; i < M; i += 8) v = v + reward(i + j);
+                    return v;
+                };
+                const double q01 = q(0) + q(1), q23 = q(2) + q(3);
+                const double lo4 = q01 + q23;
+                const double q45 = q(4) + q(5), q67 = q(6) + q(7);
+                s = lo4 + (q45 + q67);
+#pragma unroll
+                for (int i = M; i < N; ++i) s = s + reward(i);
             }
             if (a.out.d_constraints) a.out.d_constraints[e] = constraints;
             if (a.out.d_success) a.out.d_success[e] = (uint8_t)success;
             if (a.out.d_terminated) a.out.d_terminated[e] = (uint8_t)term;
-            if (a.out.d_team_reward) {  // np.sum(list)/n: numpy pairwise order (rollout.py:33)
-                double s;
-                if constexpr (N < 8) {
-                    s = 0.0;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) s = s + rew[i];
-                } else {
-                    double q[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) q[j] = rew[j];
-                    constexpr int M = N - (N % 8);
-#pragma unroll
-                    for (int i = 8; i < M; i += 8)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) q[j] = q[j] + rew[i + j];
-                    s = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-#pragma unroll
-                    for (int i = M; i < N; ++i) s = s + rew[i];
-                }
-                a.out.d_team_reward[e] = s / (double)N;
-            }
+            if (a.out.d_team_reward) a.out.d_team_reward[e] = s / (double)N;
             if (dup) r.flags = any_dup<N>(r) ? (r.flags | FLAG_DUP) : (r.flags & ~FLAG_DUP);
             ended = term && (a.flags & DMFB_STEP_AUTORESET);
             if (MAPS && (ended || log_full)) {  // the waves fold the log in after the barrier (flush_usage)
@@ -876,9 +891,8 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
                 if (lane < c.nb) p.blocks[(size_t)lane * E + (tile_base + wave * kWave + src)] = blk;
             }
             if (lane == src) {
-                int sx[N], sy[N];
-                task_to_env<N>(pts, r, sx, sy);
-                store_starts<N>(p, E, e, sx, sy);
+                task_to_env<N>(pts, r);
+                store_starts<N>(p, E, e, r.pos);
                 r.rep += 1; r.step = 0; r.cum = 0; r.flags = 0;
             }
         }
@@ -888,8 +902,8 @@ __global__ __launch_bounds__(kBlock) void k_step(DevCfg c, DevPtrs p, StepArgs a
             if (want_obs) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    t.pos[slot * N + i] = (uint32_t)r.x[i] | ((uint32_t)r.y[i] << 16);
-                    t.goal[slot * N + i] = (uint32_t)r.gx[i] | ((uint32_t)r.gy[i] << 16);
+                    t.pos[slot * N + i] = r.pos[i];
+                    t.goal[slot * N + i] = r.goal[i];
                 }
             }
             t.flag[slot] = (uint8_t)flush_kind;
@@ -1081,9 +1095,8 @@ __global__ __launch_bounds__(kBlock) void k_reset(DevCfg c, DevPtrs p, const uin
     }
     if (lane == 0) {
         EnvR<N> r;
-        int sx[N], sy[N];
-        task_to_env<N>(pts, r, sx, sy);
-        store_starts<N>(p, E, e, sx, sy);
+        task_to_env<N>(pts, r);
+        store_starts<N>(p, E, e, r.pos);
         r.step = 0; r.flags = 0; r.cum = 0; r.ulen = 0;
         r.rstep = mode == 3 ? 0u : p.st[(size_t)R::W_RSTEP * E + e];
         r.rep = rep + 1;
@@ -1109,6 +1122,10 @@ __global__ __launch_bounds__(kBlock) void k_reset(DevCfg c, DevPtrs p, const uin
 // ---- per-N launchers: declared here, defined (explicitly specialised) in dmfb_vec_n.hip -------------
 template <int N>
 hipError_t launch_step_n(const DevCfg &c, const DevPtrs &p, const StepArgs &a, int grid, size_t lds, hipStream_t s);
+// the lane-per-droplet transition (dmfb_step_lanes.h), instantiated for n >= kLanesMinN only
+constexpr int kLanesMinN = 8;
+template <int N>
+hipError_t launch_step_lanes_n(const DevCfg &c, const DevPtrs &p, const StepArgs &a, int grid, size_t lds, hipStream_t s);
 template <int N>
 hipError_t launch_reset_n(const DevCfg &c, const DevPtrs &p, const uint8_t *mask, int mode, int grid, size_t lds, hipStream_t s);
 template <int N>

@@ -172,6 +172,8 @@ struct dmfb_vec {
     int8_t *zoom_dev = nullptr;
     unsigned long long *band_dev = nullptr;  // DevPtrs::band
     int *dflags_dev = nullptr;               // DevPtrs::dflags
+    int use_lanes = 0;                       // knob: lane-per-droplet transition for n >= 8 (dmfb_step_lanes.h); off: slower
+    int obs_oneshot = 0;                     // measurement knob: k_observe with one workgroup per tile
     int obs_per_cu = 0;                      // cap on k_observe's persistent workgroups per CU (0: as many as LDS admits)
     size_t bytes = 0;
     int T_fused = 16;    // chips per workgroup of the fused step+observe launch (<= 64)
@@ -220,7 +222,8 @@ template <int N> int observe_n(const dmfb_vec *h, const uint8_t *mask, int8_t *o
     per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
     if (h->obs_per_cu > 0 && h->obs_per_cu < per_cu) per_cu = h->obs_per_cu;
     const int ntiles = (h->cfg.n_envs + T - 1) / T;
-    const int grid = ntiles < h->n_cu * per_cu ? ntiles : h->n_cu * per_cu;
+    int grid = ntiles < h->n_cu * per_cu ? ntiles : h->n_cu * per_cu;
+    if (h->obs_oneshot) grid = ntiles;  // measurement knob: one workgroup per tile, dispatched in address order
     hipEvent_t t0 = nullptr, t1 = nullptr;
     dmfb_vec *hm = const_cast<dmfb_vec *>(h);
     if (h->timing && h->timed < dmfb_vec::kTimed) {
@@ -233,16 +236,33 @@ template <int N> int observe_n(const dmfb_vec *h, const uint8_t *mask, int8_t *o
 
 // One fused launch for small batches (launch latency dominates); for large batches a step-only launch
 // (all four waves stepping, no LDS tile, high occupancy) followed by the observation kernel.
+// step-only launch (no observation tile): one lane per chip, 256 chips per workgroup.  DMFB_VEC_LANES=1 selects the
+// lane-per-droplet kernel for n >= 8 (dmfb_step_lanes.h: 16 lanes per chip) -- bit-identical, measured 1.6-1.9x SLOWER than the
+// lane-per-chip kernel, kept as the tested record of that experiment
+template <int N> int step_only_n(dmfb_vec *h, const StepArgs &b, hipStream_t s) {
+    const int E = h->cfg.n_envs;
+    DevCfg c = h->dc;
+    c.T = kStepOnlyTile;
+    if constexpr (N >= kLanesMinN) {
+        if (h->use_lanes) {
+            HIP_TRY(launch_step_lanes_n<N>(c, h->dp, b, (E + 15) / 16, hist_lds(h), s));
+            return DMFB_OK;
+        }
+    }
+    HIP_TRY(launch_step_n<N>(c, h->dp, b, (E + c.T - 1) / c.T, tile_lds_bytes(c.T, N, c.obs_len, false, 0) + hist_lds(h), s));
+    return DMFB_OK;
+}
+
 template <int N> int step_n(dmfb_vec *h, const StepArgs &a, hipStream_t s) {
     const int E = h->cfg.n_envs;
     if (a.out.d_obs && E >= h->split_min) {
         StepArgs b = a;
         b.out.d_obs = nullptr;
-        DevCfg c = h->dc;
-        c.T = kStepOnlyTile;
-        HIP_TRY(launch_step_n<N>(c, h->dp, b, (E + c.T - 1) / c.T, tile_lds_bytes(c.T, N, c.obs_len, false, 0) + hist_lds(h), s));
+        const int rc = step_only_n<N>(h, b, s);
+        if (rc) return rc;
         return observe_n<N>(h, nullptr, a.out.d_obs, s);
     }
+    if (!a.out.d_obs) return step_only_n<N>(h, a, s);
     DevCfg c = h->dc;
     const bool with_obs = a.out.d_obs != nullptr;
     c.T = with_obs ? h->T_fused : kStepOnlyTile;
@@ -426,6 +446,8 @@ int dmfb_vec_create(const dmfb_vec_config *cfg, void *stream, dmfb_vec **out) {
         if ((uint32_t)(((uint64_t)k * d.fov_magic) >> 32) != k / (uint32_t)d.fov) return fail(DMFB_ERR_UNSUPPORTED);
     h->split_min = 32768;
     if (const char *v = getenv("DMFB_VEC_SPLIT_MIN_ENVS")) h->split_min = atoi(v);  // tuning / test knob
+    if (const char *v = getenv("DMFB_VEC_LANES")) h->use_lanes = atoi(v);             // measurement / test knob: lane-per-droplet transition for n >= 8
+    if (const char *v = getenv("DMFB_VEC_OBS_ONESHOT")) h->obs_oneshot = atoi(v);     // measurement knob (see observe_n)
     if (const char *v = getenv("DMFB_VEC_OBS_PER_CU")) h->obs_per_cu = atoi(v);       // tuning knob: persistent workgroups per CU of k_observe
     rc = launch_reset(h, nullptr, 3, s);
     if (rc) return fail(rc);

@@ -65,14 +65,21 @@ __global__ __launch_bounds__(256) void k_gru_head_select(const float *__restrict
                                                          const float *__restrict__ eps_p, int evaluate, uint32_t k0, uint32_t k1,
                                                          const uint32_t *__restrict__ draw_p, int32_t *__restrict__ actions,
                                                          int8_t *__restrict__ last_onehot, int8_t *__restrict__ ep_u, int8_t *__restrict__ ep_onehot,
-                                                         int T, int t, float *__restrict__ q_out) {
+                                                         int T, int t, float *__restrict__ q_out,
+                                                         const int32_t *__restrict__ live_chips, const int32_t *__restrict__ n_live) {
     constexpr int H = 128;
     const int l32 = threadIdx.x & 31;
-    const int r = blockIdx.x * 8 + (threadIdx.x >> 5);
-    const bool live = r < rows;
-    const int rc = live ? r : rows - 1;  // dead half-waves shadow the last row (no stores) so that shuffles stay full-wave
+    // live_chips != NULL: only the rows of the listed chips; the x-side gates `ig` are COMPACT (row k*n + a of ig belongs to row
+    // live_chips[k]*n + a of everything else), as crnn_front9_forward_live leaves them
+    if (live_chips) rows = min(rows, n_live[0] * n);
+    if (blockIdx.x * 8 >= rows) return;  // (uniform) nothing live in this workgroup
+    const int cr = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool live = cr < rows;
+    const int crc = live ? cr : rows - 1;  // dead half-waves shadow the last row (no stores) so that shuffles stay full-wave
+    const int rc = live_chips ? live_chips[crc / n] * n + crc % n : crc;
+    const int r = rc;
     const int u = 4 * l32;
-    const float4 *igr = (const float4 *)(ig + (size_t)rc * 3 * H + u), *hgr = (const float4 *)(hg + (size_t)rc * 3 * H + u);
+    const float4 *igr = (const float4 *)(ig + (size_t)crc * 3 * H + u), *hgr = (const float4 *)(hg + (size_t)rc * 3 * H + u);
     const float4 i_r = igr[0], i_z = igr[H / 4], i_n = igr[2 * H / 4];
     const float4 h_r = hgr[0], h_z = hgr[H / 4], h_n = hgr[2 * H / 4];
     const float4 hx = *(const float4 *)(h + (size_t)rc * H + u);
@@ -127,6 +134,37 @@ __global__ __launch_bounds__(256) void k_gru_head_select(const float *__restrict
 }
 
 constexpr int kPostBlock = 256;
+
+// ids of the chips with alive[e] != 0, ascending, and their count: ONE workgroup walks the chips in chunks of its size, a
+// block-wide exclusive scan per chunk (stable, deterministic).  4096 chips = four chunks.
+constexpr int kCompactBlock = 1024;
+__global__ __launch_bounds__(kCompactBlock) void k_compact_alive(int E, const uint8_t *__restrict__ alive, int32_t *__restrict__ list,
+                                                                 int32_t *__restrict__ count) {
+    __shared__ int s_wave[kCompactBlock / 64];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int e0 = 0; e0 < E; e0 += kCompactBlock) {
+        const int e = e0 + tid;
+        const bool a = e < E && alive[e] != 0;
+        const unsigned long long m = __ballot(a);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (a) list[off + rank] = e;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < kCompactBlock / 64; ++w) tot += s_wave[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) count[0] = s_base;
+}
 
 // Episode observation appends of lock-step t (rollout.py:118-141 incl. the zero padding): with a = alive before the
 // step, o_next[e][t] = a ? obs[e] : 0 and o[e][t+1] = (a && !term[e]) ? obs[e] : 0 (o[t+1] of a chip that plays on IS
@@ -223,14 +261,14 @@ int rollout_select_actions(const float *d_q, int32_t n_envs, int32_t n_agents, i
     return finish();
 }
 
-int rollout_gru_head_select(const float *d_igates, const float *d_hgates, const float *d_b_ih, const float *d_b_hh, float *d_h,
-                            const float *d_fc_w, const float *d_fc_b, int32_t n_envs, int32_t n_agents, int32_t hidden,
-                            int32_t n_actions, const float *d_epsilon, int32_t evaluate, uint64_t seed, const uint32_t *d_draw,
-                            int32_t *d_actions, int8_t *d_last_onehot, int8_t *d_ep_u, int8_t *d_ep_onehot, int32_t episode_limit,
-                            int32_t t, float *d_q, void *stream) {
+static int gru_head_select_impl(const float *d_igates, const float *d_hgates, const float *d_b_ih, const float *d_b_hh, float *d_h,
+                                const float *d_fc_w, const float *d_fc_b, int32_t n_envs, int32_t n_agents, int32_t hidden,
+                                int32_t n_actions, const float *d_epsilon, int32_t evaluate, uint64_t seed, const uint32_t *d_draw,
+                                int32_t *d_actions, int8_t *d_last_onehot, int8_t *d_ep_u, int8_t *d_ep_onehot, int32_t episode_limit,
+                                int32_t t, float *d_q, const int32_t *d_live_chips, const int32_t *d_n_live, void *stream) {
     if (!d_igates || !d_hgates || !d_b_ih || !d_b_hh || !d_h || !d_fc_w || !d_fc_b || !d_actions || !d_last_onehot || n_envs < 0 ||
         n_agents < 1 || hidden != 128 || n_actions < 1 || n_actions > 16 || (!evaluate && (!d_epsilon || !d_draw)) ||
-        (d_ep_u && (t < 0 || t >= episode_limit)))
+        (d_ep_u && (t < 0 || t >= episode_limit)) || ((d_live_chips == nullptr) != (d_n_live == nullptr)))
         return ROLLOUT_ERR_BAD_ARG;
     const long rows = (long)n_envs * n_agents;
     if (rows == 0) return ROLLOUT_OK;
@@ -238,7 +276,36 @@ int rollout_gru_head_select(const float *d_igates, const float *d_hgates, const 
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_gru_head_select, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, d_igates, d_hgates, d_b_ih,
                        d_b_hh, d_h, d_fc_w, d_fc_b, (int)rows, n_agents, n_actions, d_epsilon, evaluate, (uint32_t)seed,
-                       (uint32_t)(seed >> 32), d_draw, d_actions, d_last_onehot, d_ep_u, d_ep_onehot, episode_limit, t, d_q);
+                       (uint32_t)(seed >> 32), d_draw, d_actions, d_last_onehot, d_ep_u, d_ep_onehot, episode_limit, t, d_q,
+                       d_live_chips, d_n_live);
+    return finish();
+}
+
+int rollout_gru_head_select(const float *d_igates, const float *d_hgates, const float *d_b_ih, const float *d_b_hh, float *d_h,
+                            const float *d_fc_w, const float *d_fc_b, int32_t n_envs, int32_t n_agents, int32_t hidden,
+                            int32_t n_actions, const float *d_epsilon, int32_t evaluate, uint64_t seed, const uint32_t *d_draw,
+                            int32_t *d_actions, int8_t *d_last_onehot, int8_t *d_ep_u, int8_t *d_ep_onehot, int32_t episode_limit,
+                            int32_t t, float *d_q, void *stream) {
+    return gru_head_select_impl(d_igates, d_hgates, d_b_ih, d_b_hh, d_h, d_fc_w, d_fc_b, n_envs, n_agents, hidden, n_actions, d_epsilon,
+                                evaluate, seed, d_draw, d_actions, d_last_onehot, d_ep_u, d_ep_onehot, episode_limit, t, d_q, nullptr,
+                                nullptr, stream);
+}
+
+int rollout_gru_head_select_live(const float *d_igates, const float *d_hgates, const float *d_b_ih, const float *d_b_hh, float *d_h,
+                                 const float *d_fc_w, const float *d_fc_b, int32_t n_envs, int32_t n_agents, int32_t hidden,
+                                 int32_t n_actions, const float *d_epsilon, int32_t evaluate, uint64_t seed, const uint32_t *d_draw,
+                                 int32_t *d_actions, int8_t *d_last_onehot, int8_t *d_ep_u, int8_t *d_ep_onehot, int32_t episode_limit,
+                                 int32_t t, float *d_q, const int32_t *d_live_chips, const int32_t *d_n_live, void *stream) {
+    if (!d_live_chips || !d_n_live) return ROLLOUT_ERR_BAD_ARG;
+    return gru_head_select_impl(d_igates, d_hgates, d_b_ih, d_b_hh, d_h, d_fc_w, d_fc_b, n_envs, n_agents, hidden, n_actions, d_epsilon,
+                                evaluate, seed, d_draw, d_actions, d_last_onehot, d_ep_u, d_ep_onehot, episode_limit, t, d_q, d_live_chips,
+                                d_n_live, stream);
+}
+
+int rollout_compact_alive(int32_t n_envs, const uint8_t *d_alive, int32_t *d_live_chips, int32_t *d_n_live, void *stream) {
+    if (n_envs < 0 || !d_alive || !d_live_chips || !d_n_live) return ROLLOUT_ERR_BAD_ARG;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_compact_alive, dim3(1), dim3(kCompactBlock), 0, (hipStream_t)stream, n_envs, d_alive, d_live_chips, d_n_live);
     return finish();
 }
 

@@ -431,6 +431,24 @@ class CRNN(nn.Module):
         buf[:, :w.shape[1]].copy_(w)
         return buf
 
+    def front_features_live(self, obs_i8, onehot_i8, live_chips, n_live, rows_per_chip, out):
+        """`_front_features_hip(padded=True)` for the chips listed in `live_chips` (int32, ascending; `n_live` their count, both on
+        the device) only: row k * rows_per_chip + a of `out` is the GRU input of row live_chips[k] * rows_per_chip + a of
+        obs_i8 / onehot_i8 (include/crnn_ops.h: crnn_front9_forward_live).  Rows of `out` beyond the live ones are left as they are."""
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.crnn_ops()
+        c1, c2 = self.convs[0], self.convs[1]
+        vp = C.c_void_p
+        rc = lib.crnn_front9_forward_live(vp(obs_i8.data_ptr()), obs_i8.stride(0), vp(onehot_i8.data_ptr()), self.n_actions, obs_i8.shape[0],
+                                          vp(c1.weight.data_ptr()), vp(c1.bias.data_ptr()), vp(c2.weight.data_ptr()), vp(c2.bias.data_ptr()),
+                                          vp(self.mlp1.weight.data_ptr()), vp(self.mlp1.bias.data_ptr()), c1.out_channels,
+                                          vp(out.data_ptr()), out.stride(0), out.shape[1], vp(live_chips.data_ptr()), vp(n_live.data_ptr()),
+                                          int(rows_per_chip), vp(torch.cuda.current_stream(obs_i8.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('crnn_front9_forward_live failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
+        return out
+
     def _front_features_hip(self, obs_i8, onehot_i8, padded=False):
         """GRU input x = cat([conv features, relu(mlp1([dir, last action]))]) in one HIP launch
         (include/crnn_ops.h: crnn_front9_forward / crnn_front19_forward); inference only.  padded: rows of `padded_cols()`

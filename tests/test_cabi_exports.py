@@ -84,7 +84,8 @@ def test_crnn_ops_library_exports():
     txt = open(os.path.join(ROOT, 'include', 'crnn_ops.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     names = sorted(set(re.findall(r'\b(crnn_[a-z_0-9]+)\s*\(', txt)))
-    assert names == ['crnn_conv9_backward', 'crnn_conv9_backward_parts', 'crnn_conv9_forward', 'crnn_front19_forward', 'crnn_front9_forward', 'crnn_front_padded_cols', 'crnn_last_hip_error']
+    assert names == ['crnn_conv9_backward', 'crnn_conv9_backward_parts', 'crnn_conv9_forward', 'crnn_front19_forward', 'crnn_front9_forward', 'crnn_front9_forward_live',
+                     'crnn_front_padded_cols', 'crnn_last_hip_error']
     gru = sorted(set(re.findall(r'\b(gru_[a-z_0-9]+)\s*\(', txt)))
     assert gru == ['gru_last_hip_error', 'gru_seq_backward', 'gru_seq_forward', 'gru_seq_row_blocks']
     for n in names + gru:
@@ -101,7 +102,9 @@ def test_rollout_ops_library_exports():
     txt = open(os.path.join(ROOT, 'include', 'rollout_ops.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     names = sorted(set(re.findall(r'\b(rollout_[a-z_0-9]+)\s*\(', txt)))
-    assert names == ['rollout_gru_head_select', 'rollout_last_hip_error', 'rollout_post_step', 'rollout_select_actions']
+    assert names == ['rollout_compact_alive', 'rollout_gru_head_select', 'rollout_gru_head_select_live', 'rollout_last_hip_error', 'rollout_post_step',
+                     'rollout_select_actions']
+    assert lib.rollout_compact_alive(4, None, None, None, None) == -1
     for n in names:
         assert hasattr(lib, n)
     assert lib.rollout_select_actions(None, 4, 2, 5, None, 1, 0, None, None, None, None, None, 10, 0, None) == -1

@@ -170,6 +170,20 @@ def test_lockstep_split_launch_path(monkeypatch):
     _lockstep(dict(width=12, length=9, n_agents=3, fov=7, with_maps=True), E=100, steps=60, seed=55, autoreset=True)
 
 
+def test_lockstep_lane_per_droplet_kernel(monkeypatch):
+    """The opt-in lane-per-droplet transition (csrc/dmfb_step_lanes.h, DMFB_VEC_LANES=1: 16 lanes per chip, DPP row broadcasts,
+    wave ballots for the clash test; n >= 8, step-only launches) is bit-identical to the oracle too.  It is NOT the default: it
+    measured slower than the lane-per-chip kernel."""
+    monkeypatch.setenv('DMFB_VEC_SPLIT_MIN_ENVS', '1')
+    monkeypatch.setenv('DMFB_VEC_LANES', '1')
+    _lockstep(D, E=300, steps=230, seed=53, autoreset=True, greedy=0.9)
+    _lockstep(Ecfg, E=333, steps=150, seed=54, autoreset=True, greedy=0.8)
+    _lockstep(Ecfg, E=50, steps=100, seed=32, autoreset=False, greedy=0.8)
+    _lockstep(dict(Ecfg, n_blocks=8), E=96, steps=120, seed=64, autoreset=True, greedy=0.8)
+    _lockstep(dict(width=40, length=40, n_agents=16, fov=9), E=70, steps=180, seed=56, autoreset=True, greedy=0.9)
+    _lockstep(dict(width=20, length=20, n_agents=8, fov=7, stall=False), E=90, steps=90, seed=57, autoreset=True)
+
+
 def test_lockstep_with_obstacle_blocks():
     """GenRandomBlocks (dmfb.py:228-251) through the Philox contract, _isTouchingBlocks and the block
     layer of the observation, fused and split launch shapes."""

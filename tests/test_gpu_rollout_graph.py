@@ -93,3 +93,46 @@ def test_graph_replay_sees_a_map_injected_after_capture():
         assert int(second[3].sum()) == 0 and int((second[1] != args.episode_limit).sum()) == 0, 'droplets moved on dead electrodes'
     for k in range(4):
         assert torch.equal(outs[0][1][k], outs[1][1][k]), ('stat after set_map', k)
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_rollout_skipping_finished_chips_equals_the_full_batch_rollout(use_graph):
+    """Chips whose episode is over are kept out of the conv front end and the GRU-head kernel (Evaluator.compact_every; the list of
+    live chips is rebuilt on the device every k lock-steps).  Episodes, statistics and the epsilon schedule must not change.
+    Tasks: every droplet one cell from its goal (or on it), fully random actions, so chips finish at scattered times."""
+    from marl_dmfb_amd.env.dmfb import VecDMFB
+    E, n = 300, 4
+    rng = torch.Generator().manual_seed(3)
+    starts = torch.zeros((E, n, 2), dtype=torch.int32)
+    starts[:, :, 0] = torch.tensor([1, 4, 7, 4])
+    starts[:, :, 1] = torch.tensor([1, 4, 7, 8])
+    ends = starts.clone()
+    off = torch.randint(0, 3, (E, n), generator=rng)        # 0: on the goal, 1 / 2: one cell away in x / y
+    ends[:, :, 0] += (off == 1).int()
+    ends[:, :, 1] -= (off == 2).int()
+    outs = []
+    for every in (0, 1, 4):
+        tr = _trainer(use_graph)
+        env = tr.env
+        assert env.n_envs == 256
+        env.set_task(starts[:256], ends[:256])
+        w = tr.rolloutWorker
+        w.reset_fn = env.restart
+        w.compact_every = every
+        w.epsilon = torch.tensor(1.0, device='cuda')
+        res = []
+        for _ in range(2):
+            r = w.generate_episode()
+            res.append((tuple(x.clone() for x in r[:4]), {k: v.clone() for k, v in r[4].items()}, float(w.epsilon)))
+        outs.append(res)
+        ended = r[1] < tr.args.episode_limit
+        assert 0.5 < float(ended.float().mean()), 'the scenario must make most chips finish early'
+        lengths = (~r[4]['padded'][:, :, 0]).sum(1)
+        assert len(torch.unique(lengths)) > 5
+    for other in outs[1:]:
+        for (sa, ea, epa), (sb, eb, epb) in zip(outs[0], other):
+            for k in range(4):
+                assert torch.equal(sa[k], sb[k]), ('stat', k)
+            for key in ea:
+                assert torch.equal(ea[key], eb[key]), key
+            assert epa == epb

@@ -143,3 +143,85 @@ def test_gru_head_select_matches_grucell_and_linear(A, H):
     np.testing.assert_allclose(q.cpu().numpy(), q_ref.cpu().numpy(), rtol=0, atol=1e-5)
     assert torch.equal(actions.long(), q.argmax(dim=1))
     assert torch.equal(last, torch.nn.functional.one_hot(actions.long(), A).to(torch.int8))
+
+
+def test_compact_alive_lists_live_chips_in_order():
+    from marl_dmfb_amd import _lib
+    lib = _lib.rollout_ops()
+    vp = C.c_void_p
+    for E, p in ((1, 1.0), (37, 0.5), (1024, 0.3), (4096, 0.65), (5000, 0.0), (9001, 0.9)):
+        g = torch.Generator(device='cuda').manual_seed(E)
+        alive = (torch.rand(E, device='cuda', generator=g) < p).to(torch.uint8)
+        lst = torch.full((E,), -7, dtype=torch.int32, device='cuda')
+        cnt = torch.full((1,), -1, dtype=torch.int32, device='cuda')
+        assert lib.rollout_compact_alive(E, vp(alive.data_ptr()), vp(lst.data_ptr()), vp(cnt.data_ptr()), None) == 0
+        want = torch.nonzero(alive).reshape(-1).to(torch.int32)
+        k = int(cnt.item())
+        assert k == want.numel()
+        assert torch.equal(lst[:k], want) and bool((lst[k:] == -7).all())
+
+
+def test_live_row_kernels_match_the_full_ones():
+    """crnn_front9_forward_live / rollout_gru_head_select_live (the rollout's kernels for the chips still playing) against the
+    full-batch kernels: same values, compact x rows, finished chips untouched."""
+    import types
+    from marl_dmfb_amd import _lib
+    from marl_dmfb_amd.network.base_net import CRNN
+    lib = _lib.rollout_ops()
+    vp = C.c_void_p
+    E, n, A, H, T, t = 203, 4, 5, 128, 7, 3
+    torch.manual_seed(4)
+    net = CRNN(types.SimpleNamespace(obs_shape=(3, 9, 9, 2, 245), hyper_hidden_dim=24, rnn_hidden_dim=H, n_actions=A, fov=9)).cuda()
+    g = torch.Generator(device='cuda').manual_seed(1)
+    obs = torch.randint(0, 5, (E * n, 245), device='cuda', generator=g, dtype=torch.int8)
+    la = torch.zeros((E * n, A), dtype=torch.int8, device='cuda')
+    la[torch.arange(E * n), torch.randint(0, A, (E * n,), device='cuda', generator=g)] = 1
+    alive = (torch.rand(E, device='cuda', generator=g) < 0.6).to(torch.uint8)
+    lst = torch.empty(E, dtype=torch.int32, device='cuda')
+    cnt = torch.zeros(1, dtype=torch.int32, device='cuda')
+    assert lib.rollout_compact_alive(E, vp(alive.data_ptr()), vp(lst.data_ptr()), vp(cnt.data_ptr()), None) == 0
+    k = int(cnt.item())
+    rows = (lst[:k].long()[:, None] * n + torch.arange(n, device='cuda')[None]).reshape(-1)
+    with torch.no_grad():
+        x_full = net._front_features_hip(obs, la, padded=True)
+        x_live = torch.full_like(x_full, 123.0)
+        net.front_features_live(obs, la, lst, cnt, n, x_live)
+    assert torch.equal(x_live[:k * n], x_full[rows])
+    assert bool((x_live[k * n:] == 123.0).all())                      # rows beyond the live ones are not written
+    # head + pick: ig compact, everything else in chip order
+    ig_full = torch.randn(E * n, 3 * H, device='cuda', generator=g)
+    hg = torch.randn(E * n, 3 * H, device='cuda', generator=g)
+    h0 = torch.randn(E * n, H, device='cuda', generator=g)
+    ig_live = torch.zeros_like(ig_full)
+    ig_live[:k * n] = ig_full[rows]
+    eps = torch.tensor([0.3], device='cuda')
+    draw = torch.tensor([5], dtype=torch.int32, device='cuda')
+    outs = []
+    for live in (False, True):
+        h = h0.clone()
+        actions = torch.full((E * n,), -1, dtype=torch.int32, device='cuda')
+        last = torch.full((E * n, A), 9, dtype=torch.int8, device='cuda')
+        ep_u = torch.zeros((E, T, n, 1), dtype=torch.int8, device='cuda')
+        ep_oh = torch.zeros((E, T, n, A), dtype=torch.int8, device='cuda')
+        q = torch.zeros((E * n, A), device='cuda')
+        args = [vp(net.rnn.bias_ih.data_ptr()), vp(net.rnn.bias_hh.data_ptr()), vp(h.data_ptr()), vp(net.fc1.weight.data_ptr()),
+                vp(net.fc1.bias.data_ptr()), E, n, H, A, vp(eps.data_ptr()), 0, 77, vp(draw.data_ptr()), vp(actions.data_ptr()),
+                vp(last.data_ptr()), vp(ep_u.data_ptr()), vp(ep_oh.data_ptr()), T, t, vp(q.data_ptr())]
+        if live:
+            rc = lib.rollout_gru_head_select_live(vp(ig_live.data_ptr()), vp(hg.data_ptr()), *args, vp(lst.data_ptr()), vp(cnt.data_ptr()), None)
+        else:
+            rc = lib.rollout_gru_head_select(vp(ig_full.data_ptr()), vp(hg.data_ptr()), *args, None)
+        assert rc == 0
+        outs.append((h, actions, last, ep_u, ep_oh, q))
+    full, lv = outs
+    dead = torch.ones(E * n, dtype=torch.bool, device='cuda')
+    dead[rows] = False
+    for a, b in zip(full, lv):
+        if a.dim() == 4:   # episode tensors (E, T, n, .): slot t of the live rows; finished chips stay zero
+            a2, b2 = a[:, t].reshape(E * n, -1), b[:, t].reshape(E * n, -1)
+            assert int(b2[dead].abs().sum()) == 0 and int(b.abs().sum()) == int(b[:, t].abs().sum())
+        else:
+            a2, b2 = a.reshape(E * n, -1), b.reshape(E * n, -1)
+        assert torch.equal(a2[rows], b2[rows])
+    assert torch.equal(lv[0][dead], h0[dead])                          # hidden state of finished chips untouched
+    assert bool((lv[1][dead] == -1).all()) and bool((lv[2][dead] == 9).all())

@@ -52,9 +52,9 @@ def launch_labels(name, cfg, env, E):
     ob = n * (3 * fov * fov + 2)
     maps = 'true' if cfg.get('b_degrade') else 'false'
     if E >= sh['split_min_envs']:
-        out['dmfbk::k_step<%d, %s>|%d' % (n, maps, wgs(sh['step_only_tile']))] = {'key': 'k_step_only_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (algo_bytes(cfg) - ob) * E}
+        out['dmfbk::k_step<%d, %s, false>|%d' % (n, maps, wgs(sh['step_only_tile']))] = {'key': 'k_step_only_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (algo_bytes(cfg) - ob) * E}
     else:
-        out['dmfbk::k_step<%d, %s>|%d' % (n, maps, wgs(sh['fused_tile']))] = {'key': 'k_step_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': algo_bytes(cfg) * E}
+        out['dmfbk::k_step<%d, %s, true>|%d' % (n, maps, wgs(sh['fused_tile']))] = {'key': 'k_step_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': algo_bytes(cfg) * E}
     out['dmfbk::k_observe<%d>|%d' % (n, sh['observe_workgroups'] * sh['observe_block'])] = {'key': 'k_observe_%dx%d_%dd_E%d' % (W, L, n, E), 'algo_bytes': (ob + 5 * n + 8) * E}
     return out
 

@@ -9,6 +9,7 @@
 
 usage: reduce_profiles.py trace <dir with *_kernel_trace.csv> <out csv> [name filter regex]
        reduce_profiles.py traffic <fetch dir> <write dir> <traffic.json> <labels.json>
+       reduce_profiles.py pmc <dir with one sub-directory per --pmc pass> <out json> [name filter regex]
 """
 import csv
 import glob
@@ -103,8 +104,39 @@ def reduce_traffic(fetch_dir, write_dir, out_json, labels_json):
     return res
 
 
+def reduce_pmc(root, out_json, flt=None):
+    """Every *_counter_collection.csv below `root` (one sub-directory per --pmc pass) -> {kernel|grid: {counter: average per
+    dispatch, 'dispatches': n, 'avg_ns': kernel time from the same pass}} ; the first quarter of the dispatches is dropped."""
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in pmc_rows(root):
+        name = short(r['Kernel_Name'])
+        if flt and not re.search(flt, name):
+            continue
+        key = '%s|%s' % (name, r['Grid_Size'])
+        acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
+        if 'Start_Timestamp' in r and r.get('End_Timestamp'):
+            acc[key]['_ns_' + r['Counter_Name']].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+    res = {}
+    for key, cs in acc.items():
+        row = {}
+        for c, v in cs.items():
+            v = v[len(v) // 4:]
+            if c.startswith('_ns_'):
+                row.setdefault('avg_ns_by_pass', {})[c[4:]] = round(sum(v) / len(v), 1)
+            else:
+                row[c] = round(sum(v) / len(v), 2)
+                row['dispatches'] = len(v)
+        res[key] = row
+    with open(out_json, 'w') as fh:
+        json.dump(res, fh, indent=1, sort_keys=True)
+    return res
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'trace':
+    if sys.argv[1] == 'pmc':
+        r = reduce_pmc(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+        print(json.dumps(sorted(r)))
+    elif sys.argv[1] == 'trace':
         print(reduce_trace(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None))
     elif sys.argv[1] == 'traffic':
         r = reduce_traffic(*sys.argv[2:6])
