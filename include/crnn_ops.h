@@ -78,6 +78,17 @@ int crnn_conv9_backward_parts(int od);
 int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
                         const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1, const float *d_w2,
                         int od, float *d_part, int n_part, float *d_grads, void *stream);
+/* Gradients of the fov-19 conv stack (conv_str(19) of network/base_net.py:23-33: stride-2 conv1, then the tied conv3 twice) for
+ * the eval network of VDN.learn on MEDA: d_out = crnn_front19_forward's output (its sign is the last ReLU's mask), d_grad_out the
+ * gradient w.r.t. it (only the first od*25 columns of a row are read).  Nothing is saved by the forward: a1 and a2 of each row
+ * block are recomputed on the matrix cores; conv3's two applications add into ONE weight gradient.  One persistent workgroup
+ * per partial vector (n_part <= 256) accumulates over its rows into d_part float32[n_part][crnn_conv19_backward_parts(od)]
+ * (scratch); a second small kernel adds the partial vectors in a fixed order (deterministic) into
+ * d_grads float32[od*od*9 + od + od*27 + od] = dW3[od][od][3][3] | db3[od] | dW1[od][3][3][3] | db1[od]. */
+int crnn_conv19_backward_parts(int od);
+int crnn_conv19_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
+                         const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1, const float *d_w3,
+                         const float *d_b3, int od, float *d_part, int n_part, float *d_grads, void *stream);
 int crnn_last_hip_error(void);
 
 /* ---- GRU cell unrolled over an episode (network/base_net.py:56,69 nn.GRUCell; policy/vdn.py:174-191 time loop) ----

@@ -150,10 +150,12 @@ __global__ __launch_bounds__(kBlockM, RBV == 0 ? 2 : 4) void k_conv9_mfma(const 
     if (live_chips) rows = min(rows, (long)n_live[0] * rows_per_chip);
     const long n_blocks = (rows + G::RB - 1) / G::RB;
     const int nin = 2 + n_actions;
+    // cr / rows_per_chip as a multiply-high (exact for cr * rows_per_chip < 2^32: the host checks the row count)
+    const uint32_t rpc_magic = (uint32_t)(0x100000000ull / (uint32_t)(rows_per_chip > 0 ? rows_per_chip : 1)) + 1u;
     auto src_row = [&](long cr) -> long {  // compact row -> row of the input tensors
         if (!live_chips) return cr;
-        const long k = cr / rows_per_chip;
-        return (long)live_chips[k] * rows_per_chip + (cr - k * rows_per_chip);
+        const uint32_t k = __umulhi((uint32_t)cr, rpc_magic);
+        return (long)((uint32_t)live_chips[k] * (uint32_t)rows_per_chip + ((uint32_t)cr - k * (uint32_t)rows_per_chip));
     };
     // The bytes of block i+1 are fetched into registers while block i is in conv1 and parked in LDS once conv1 is
     // done with s_in: the HBM latency of the int8 rows never sits between two barriers.
@@ -198,19 +200,28 @@ __global__ __launch_bounds__(kBlockM, RBV == 0 ? 2 : 4) void k_conv9_mfma(const 
             // (quarter qt: p = 16 qt + i), position 48 of all RB rows is one more tile.  Wave `sub` takes rows
             // sub, sub + 4, ...: three accumulator chains per row; the gathers of the next row are in flight while
             // the MFMAs of the current one issue.  Addresses are per-lane constants + compile-time offsets.
-            float cv[2][3][7];
+            // (RBV != 0: two workgroups per CU, 128 registers per lane: the gathers are not double-buffered -- the other
+            // workgroup's waves cover their latency)
+            constexpr int NB = RBV ? 1 : 2;
+            float cv[NB][3][7];
 #pragma unroll
             for (int qt = 0; qt < 3; ++qt)
 #pragma unroll
                 for (int s = 0; s < 7; ++s) cv[0][qt][s] = s_in[sub * G::IN_STRIDE + goff[qt] + off1[s]];
 #pragma unroll
             for (int i = 0; i < G::RB / 4; ++i) {
-                if (i + 1 < G::RB / 4) {
+                if (NB == 1 && i > 0) {
+#pragma unroll
+                    for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+                        for (int s = 0; s < 7; ++s) cv[0][qt][s] = s_in[(sub + 4 * i) * G::IN_STRIDE + goff[qt] + off1[s]];
+                }
+                if (NB == 2 && i + 1 < G::RB / 4) {
 #pragma unroll
                     for (int qt = 0; qt < 3; ++qt)
 #pragma unroll
                         for (int s = 0; s < 7; ++s)
-                            cv[(i + 1) & 1][qt][s] = s_in[(sub + 4 * (i + 1)) * G::IN_STRIDE + goff[qt] + off1[s]];
+                            cv[(i + 1) & (NB - 1)][qt][s] = s_in[(sub + 4 * (i + 1)) * G::IN_STRIDE + goff[qt] + off1[s]];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc[3];
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(kBlockM, RBV == 0 ? 2 : 4) void k_conv9_mfma(const 
 #pragma unroll
                 for (int s = 0; s < 7; ++s)
 #pragma unroll
-                    for (int qt = 0; qt < 3; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i & 1][qt][s], bw1[s], acc[qt], 0, 0, 0);
+                    for (int qt = 0; qt < 3; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i & (NB - 1)][qt][s], bw1[s], acc[qt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (chv) {
                     float *dst = s_a1 + (sub + 4 * i) * G::ROW_A1 + ch * G::CS + kq * 4;
@@ -253,8 +264,12 @@ __global__ __launch_bounds__(kBlockM, RBV == 0 ? 2 : 4) void k_conv9_mfma(const 
 #ifndef CRNN_PROBE_SKIP_CONV2
         {
             int t = sub;
-            for (; t + 4 < G::T2; t += 8) conv2_tiles<OD, RBV, 2>(s_a1, s_out, bw2, bias2, t, t + 4, j, kq, ch, chv);
-            if (t < G::T2) conv2_tiles<OD, RBV, 1>(s_a1, s_out, bw2, bias2, t, t, j, kq, ch, chv);
+            if constexpr (RBV == 0) {  // two tiles (two accumulator chains) in flight per wave
+                for (; t + 4 < G::T2; t += 8) conv2_tiles<OD, RBV, 2>(s_a1, s_out, bw2, bias2, t, t + 4, j, kq, ch, chv);
+                if (t < G::T2) conv2_tiles<OD, RBV, 1>(s_a1, s_out, bw2, bias2, t, t, j, kq, ch, chv);
+            } else {
+                for (; t < G::T2; t += 4) conv2_tiles<OD, RBV, 1>(s_a1, s_out, bw2, bias2, t, t, j, kq, ch, chv);
+            }
         }
 #endif
         if (mlp_w && tid < G::RB * 10) s_out[mr * G::OUT_STRIDE + OD * 25 + mc] = fmaxf(mv, 0.0f);

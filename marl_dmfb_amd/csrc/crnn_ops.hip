@@ -20,6 +20,7 @@
 #include "../../include/crnn_ops.h"
 #include "crnn_mfma.h"
 #include "crnn_mfma19.h"
+#include "crnn_bwd19.h"
 
 namespace {
 
@@ -482,6 +483,28 @@ int launch_bwd(const int8_t *obs, long obs_stride, long rows, const float *a2, l
     return CRNN_OK;
 }
 
+template <int OD>
+int launch_bwd19(const int8_t *obs, long obs_stride, long rows, const float *a3, long a3_stride, const float *g, long g_stride,
+                 const float *w1, const float *b1, const float *w3, const float *b3, float *part, int n_part, float *grads, hipStream_t s) {
+    using G = crnn_bwd19::GeoB19<OD>;
+    const size_t lds = G::LDS_FLOATS * sizeof(float);
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
+        hipError_t e = hipFuncSetAttribute((const void *)crnn_bwd19::k_conv19_bwd<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
+        attr_set.mark();
+    }
+    const long n_blocks = (rows + G::RBB - 1) / G::RBB;
+    const int grid = (int)(n_blocks < n_part ? n_blocks : n_part);  // one persistent workgroup per partial vector (<= 256: one per CU)
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((crnn_bwd19::k_conv19_bwd<OD>), dim3(grid), dim3(crnn_bwd19::kBlockB), lds, s, obs, obs_stride, rows, a3, a3_stride, g,
+                       g_stride, w1, b1, w3, b3, part);
+    hipLaunchKernelGGL((crnn_bwd19::k_conv19_bwd_reduce<OD>), dim3((G::GRADS + 255) / 256), dim3(256), 0, s, part, grid, grads);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
+    return CRNN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -515,7 +538,7 @@ int crnn_front9_forward_live(const int8_t *d_obs, int64_t obs_stride, const int8
                              const int32_t *d_n_live, int rows_per_chip, void *stream) {
     if (!d_obs || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_mlp_w || !d_mlp_b || !d_out || rows < 0 || obs_stride < 245 ||
         out_stride < od * 25 + 10 || n_actions < 0 || n_actions > 16 || !d_live_chips || !d_n_live || rows_per_chip < 1 ||
-        rows % rows_per_chip != 0)
+        rows_per_chip > 64 || rows % rows_per_chip != 0 || rows >= (1 << 25))
         return CRNN_ERR_BAD_ARG;
     if (od != 24 && od != 32) return CRNN_ERR_UNSUPPORTED;
     if (out_cols != 0 && (out_cols < od * 25 + 10 || out_cols > crnn_front_padded_cols(od) || out_cols > out_stride)) return CRNN_ERR_BAD_ARG;
@@ -551,6 +574,19 @@ int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, c
         return CRNN_ERR_BAD_ARG;
     if (od == 24) return launch_bwd<24>(d_obs, obs_stride, rows, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, d_w1, d_b1, (hipStream_t)stream);
     if (od == 32) return launch_bwd<32>(d_obs, obs_stride, rows, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, d_w1, d_b1, (hipStream_t)stream);
+    return CRNN_ERR_UNSUPPORTED;
+}
+
+int crnn_conv19_backward_parts(int od) { return od == 24 ? crnn_bwd19::GeoB19<24>::PART : od == 32 ? crnn_bwd19::GeoB19<32>::PART : CRNN_ERR_UNSUPPORTED; }
+
+int crnn_conv19_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
+                         const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1, const float *d_w3,
+                         const float *d_b3, int od, float *d_part, int n_part, float *d_grads, void *stream) {
+    if (!d_obs || !d_out || !d_grad_out || !d_w1 || !d_b1 || !d_w3 || !d_b3 || !d_part || !d_grads || rows <= 0 || n_part < 1 ||
+        n_part > 256 || obs_stride < 3 * 19 * 19 || out_stride < od * 25 || grad_stride < od * 25)
+        return CRNN_ERR_BAD_ARG;
+    if (od == 24) return launch_bwd19<24>(d_obs, obs_stride, rows, d_out, out_stride, d_grad_out, grad_stride, d_w1, d_b1, d_w3, d_b3, d_part, n_part, d_grads, (hipStream_t)stream);
+    if (od == 32) return launch_bwd19<32>(d_obs, obs_stride, rows, d_out, out_stride, d_grad_out, grad_stride, d_w1, d_b1, d_w3, d_b3, d_part, n_part, d_grads, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
 }
 

@@ -7,6 +7,8 @@ checkpoints load unchanged.  Two additions for the vectorised loop:
   * `forward_obs()` takes the int8 observation rows the HIP env writes plus the last-action
     one-hot, so the rollout never materialises the concatenated float input on the host.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as f
@@ -136,6 +138,59 @@ class _Front9Train(torch.autograd.Function):
         vec = torch.cat([obs_i8[:, 243:245].float(), onehot_i8.float()], dim=1)
         g_mw = _wgrad_splitk(gz.contiguous(), vec)
         return (None, None, tot[n2 + od:n2 + od + od * 27].view(s1), tot[n2 + od + od * 27:], tot[:n2].view(s2), tot[n2:n2 + od],
+                g_mw, _colsum(gz), None)
+
+
+class _Front19Train(torch.autograd.Function):
+    """The GRU input row of the eval network for fov 19 (MEDA): x = cat([conv features, relu(mlp1([dir, last action]))]) in ONE
+    launch (crnn_front19_forward: stride-2 conv1, then the tied conv3 twice) with a hand-written backward
+    (crnn_conv19_backward: recomputes a1 / a2 on the matrix cores, transposed convolutions in gather form, both applications of
+    conv3 add into one weight gradient) and two small split-K GEMMs for mlp1."""
+
+    @staticmethod
+    def forward(ctx, obs_i8, onehot_i8, w1, b1, w3, b3, mlp_w, mlp_b, cols):
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.crnn_ops()
+        vp = C.c_void_p
+        obs_i8, onehot_i8 = obs_i8.contiguous(), onehot_i8.contiguous()
+        R, od, A = obs_i8.shape[0], w1.shape[0], onehot_i8.shape[1]
+        x = torch.empty((R, cols), dtype=torch.float32, device=obs_i8.device)
+        w1c, b1c, w3c, b3c, mwc, mbc = (t.detach().contiguous() for t in (w1, b1, w3, b3, mlp_w, mlp_b))
+        rc = lib.crnn_front19_forward(vp(obs_i8.data_ptr()), obs_i8.stride(0), vp(onehot_i8.data_ptr()), A, R, vp(w1c.data_ptr()),
+                                      vp(b1c.data_ptr()), vp(w3c.data_ptr()), vp(b3c.data_ptr()), vp(mwc.data_ptr()),
+                                      vp(mbc.data_ptr()), od, vp(x.data_ptr()), x.stride(0), cols,
+                                      vp(torch.cuda.current_stream(obs_i8.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('crnn_front19_forward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
+        ctx.save_for_backward(obs_i8, onehot_i8, x, w1c, b1c, w3c, b3c)
+        ctx.shapes = (w1.shape, w3.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.crnn_ops()
+        vp = C.c_void_p
+        obs_i8, onehot_i8, x, w1c, b1c, w3c, b3c = ctx.saved_tensors
+        (s1, s3) = ctx.shapes
+        od = s1[0]
+        if g.stride(1) != 1:
+            g = g.contiguous()
+        R = obs_i8.shape[0]
+        n3 = od * od * 9
+        tot = torch.empty(n3 + od + od * 27 + od, dtype=torch.float32, device=g.device)
+        part = torch.empty((N_PART, lib.crnn_conv19_backward_parts(od)), dtype=torch.float32, device=g.device)
+        rc = lib.crnn_conv19_backward(vp(obs_i8.data_ptr()), obs_i8.stride(0), R, vp(x.data_ptr()), x.stride(0), vp(g.data_ptr()),
+                                      g.stride(0), vp(w1c.data_ptr()), vp(b1c.data_ptr()), vp(w3c.data_ptr()), vp(b3c.data_ptr()), od,
+                                      vp(part.data_ptr()), N_PART, vp(tot.data_ptr()), vp(torch.cuda.current_stream(g.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('crnn_conv19_backward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
+        gz = g[:, od * 25:od * 25 + 10] * (x[:, od * 25:od * 25 + 10] > 0)
+        vec = torch.cat([obs_i8[:, 1083:1085].float(), onehot_i8.float()], dim=1)
+        g_mw = _wgrad_splitk(gz.contiguous(), vec)
+        return (None, None, tot[n3 + od:n3 + od + od * 27].view(s1), tot[n3 + od + od * 27:], tot[:n3].view(s3), tot[n3:n3 + od],
                 g_mw, _colsum(gz), None)
 
 
@@ -481,6 +536,9 @@ class CRNN(nn.Module):
         """GRU input rows for the eval network inside learn (gradients flow to every parameter):
         HIP conv front end with its own backward + the small vector MLP in torch."""
         c1, c2 = self.convs[0], self.convs[1]
+        if self._hip_geometry() == 19:  # tied conv3: autograd adds the gradient this node returns for it ONCE (both applications inside)
+            return _Front19Train.apply(obs_i8, la_rows.to(torch.int8), c1.weight, c1.bias, c2.weight, c2.bias,
+                                       self.mlp1.weight, self.mlp1.bias, self.padded_cols())
         if self.mlp1.in_features == 2 + self.n_actions and self.n_actions <= 16 and self.mlp1.out_features == 10:
             return _Front9Train.apply(obs_i8, la_rows.to(torch.int8), c1.weight, c1.bias, c2.weight, c2.bias,
                                       self.mlp1.weight, self.mlp1.bias, self.padded_cols())
@@ -489,9 +547,13 @@ class CRNN(nn.Module):
         return torch.cat([pix, f.relu(self.mlp1(vec))], dim=1)
 
     def _hip_train_ok(self, obs_i8):
-        return (self.conv_impl == 'gemm' and obs_i8.is_cuda and obs_i8.dtype == torch.int8 and torch.is_grad_enabled()
-                and self.input_dim[:3] == (3, 9, 9) and len(self.convs) == 2 and self.convs[0].out_channels in (24, 32)
-                and self.convs[0] is not self.convs[1])
+        if not (self.conv_impl == 'gemm' and obs_i8.is_cuda and obs_i8.dtype == torch.int8 and torch.is_grad_enabled()
+                and self.convs[0].out_channels in (24, 32)):
+            return False
+        if self._hip_geometry() == 19:   # MEDA: stride-2 conv1 + the tied conv3 twice (crnn_conv19_backward)
+            return (self.mlp1.in_features == 2 + self.n_actions and self.n_actions <= 16 and self.mlp1.out_features == 10
+                    and os.environ.get('MARL_DMFB_CONV19_BWD', '1') != '0')
+        return (self.input_dim[:3] == (3, 9, 9) and len(self.convs) == 2 and self.convs[0] is not self.convs[1])
 
     def _hip_geometry(self):
         """9 / 19: the conv stack is one of the two the HIP front-end kernels implement (conv_str(9): conv1, conv3;

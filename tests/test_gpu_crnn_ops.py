@@ -277,3 +277,57 @@ def test_front_end_zero_padded_rows(fov, od, rows):
             np.testing.assert_allclose(ig.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=2e-5)
             net.rnn.weight_ih.grad = torch.randn_like(net.rnn.weight_ih)
             opt.step()
+
+
+def _safe_rows19(net, obs, margin=2e-5):
+    """_safe_rows for the fov-19 stack: rows none of whose three conv pre-activations lies within `margin` of zero."""
+    c1, c3 = net.convs[0], net.convs[1]
+    R = obs.shape[0]
+    x = obs[:, :1083].double().view(-1, 3, 19, 19)
+    z1 = torch.nn.functional.conv2d(x, c1.weight.double(), c1.bias.double(), stride=2)
+    z2 = torch.nn.functional.conv2d(torch.relu(z1), c3.weight.double(), c3.bias.double())
+    z3 = torch.nn.functional.conv2d(torch.relu(z2), c3.weight.double(), c3.bias.double())
+    ok = torch.ones(R, dtype=torch.bool, device=obs.device)
+    for z in (z1, z2, z3):
+        ok &= z.abs().reshape(R, -1).min(dim=1).values > margin
+    return ok
+
+
+@pytest.mark.parametrize('od,rows', [(32, 3001), (24, 4000), (32, 2), (24, 5), (32, 770)])
+def test_front19_train_node_matches_torch_autograd(od, rows):
+    """_Front19Train (crnn_front19_forward + crnn_conv19_backward: a1 / a2 recomputed on the matrix cores, transposed
+    convolutions in gather form, the tied conv3's two applications summed into one gradient) against float64 torch autograd
+    of the reference network's fov-19 front end (network/base_net.py:23-33, 59-68); tolerance GRAD_TOL."""
+    from marl_dmfb_amd.network.base_net import CRNN, _Front19Train
+    a = _args19(od)
+    torch.manual_seed(od * 7 + rows)
+    net = CRNN(a).cuda()
+    assert net._hip_geometry() == 19
+    obs = torch.randint(0, 6, (rows, 1085), dtype=torch.int8, device='cuda')
+    obs[:, 1083:] = torch.randint(-10, 11, (rows, 2), dtype=torch.int8, device='cuda')
+    oh = torch.nn.functional.one_hot(torch.randint(0, 9, (rows,), device='cuda'), 9).to(torch.int8)
+    nf = od * 25 + 10
+    cols = net.padded_cols() if rows % 2 else nf
+    gfull = torch.randn(rows, cols, device='cuda')
+    safe = _safe_rows19(net, obs)
+    assert float(safe.float().mean()) > 0.7
+    gfull[:, :nf] *= safe[:, None]
+    gout = gfull[:, :nf]
+    c1, c3 = net.convs[0], net.convs[1]
+    xfull = _Front19Train.apply(obs, oh, c1.weight, c1.bias, c3.weight, c3.bias, net.mlp1.weight, net.mlp1.bias, cols)
+    assert xfull.shape == (rows, cols) and bool((xfull[:, nf:] == 0).all())
+    (xfull * gfull).sum().backward()
+    params = (c1.weight, c1.bias, c3.weight, c3.bias, net.mlp1.weight, net.mlp1.bias)
+    got = [p.grad.detach().cpu().clone() for p in params]
+    ref = CRNN(a).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in net.state_dict().items()})
+    inp = torch.cat([obs.double().cpu(), oh.double().cpu()], dim=1)
+    xr = ref.features(inp)
+    np.testing.assert_allclose(xfull[:, :nf].detach().cpu().numpy(), xr.detach().numpy(), rtol=1e-4, atol=1e-4)
+    (xr * gout.double().cpu()).sum().backward()
+    r1, r3 = ref.convs[0], ref.convs[1]
+    for name, g, r in zip(('w1', 'b1', 'w3', 'b3', 'mlp_w', 'mlp_b'), got,
+                          (r1.weight.grad, r1.bias.grad, r3.weight.grad, r3.bias.grad, ref.mlp1.weight.grad, ref.mlp1.bias.grad)):
+        err = _rel_l2(g.numpy(), r.numpy())
+        print('front19 od=%d rows=%d %s rel_l2=%.2e' % (od, rows, name, err))
+        assert err <= GRAD_TOL, (name, err)

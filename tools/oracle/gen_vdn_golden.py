@@ -157,7 +157,7 @@ def gen_rollout(seed, n_tasks):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['small', 'b64', 'rollout']
+    which = sys.argv[1:] or ['small', 'b64', 'rollout', 'meda']
     if 'small' in which:
         gen_learn('4d_od24', 4, 10, 10, 9, B=6, seed=5)
         gen_learn('10d_od32', 10, 20, 20, 9, B=3, seed=6)
@@ -167,3 +167,83 @@ if __name__ == '__main__':
         gen_learn('4d_od24_b64', 4, 10, 10, 9, B=64, seed=7)
     if 'rollout' in which:
         gen_rollout(seed=2, n_tasks=16)
+
+
+def gen_learn_meda(tag, seed):
+    """VDN.learn on the MEDA network shape (fov 19: stride-2 conv1, then the tied conv3 twice; 9 actions).  The reference's MEDA
+    TRAINING path is broken (get_env_info returns an int where a tuple is indexed, meda.py:676-681), so the batch is assembled
+    here from the reference's own MEDAEnv_v0_2 (observations, rewards, dones of random play) in the replay buffer's layout
+    (common/replay_buffer.py:10-28) and handed to the reference's Agents.train / VDN.learn with the tuple obs_shape the network
+    needs."""
+    import random
+    from env.MEDA.meda import MEDAEnv_v0_2
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    random.seed(seed)
+    W = L = 30
+    n, fov, A, T = 4, 19, 9, 16
+    O = 3 * fov * fov + 2
+    with open('/root/reference/data-meda/TrainParas/4d.yaml') as f:
+        net, train = yaml.safe_load_all(f.read())
+    a = types.SimpleNamespace(alg='vdn', net='crnn', last_action=True, reuse_network=True, cuda=False, optimizer='ADAM',
+                              gamma=0.99, model_dir='/tmp/model', load_model=False, load_model_name='', ith_run=0,
+                              fov=fov, width=W, length=L, drop_num=n, block_num=0, stall=True)
+    a.__dict__.update(net)
+    a.__dict__.update(train)
+    a.__dict__.update(n_actions=A, n_agents=n, obs_shape=(3, fov, fov, 2, O), episode_limit=T)
+    agents = Agents(a)
+    det_init(agents.policy.eval_rnn)
+    det_init(agents.policy.target_rnn, salt=0.5)
+    assert agents.policy.eval_rnn.convs[1] is agents.policy.eval_rnn.convs[2]     # the tied conv3
+    env = MEDAEnv_v0_2(W, L, n, fov=fov)
+    lens = [12, 7, 16, 9, 5]
+    B = len(lens)
+    batch = {'o': np.zeros((B, T, n, O)), 'u': np.zeros((B, T, n, 1)), 'r': np.zeros((B, T, 1)), 'o_next': np.zeros((B, T, n, O)),
+             'avail_u': np.zeros((B, T, n, A)), 'avail_u_next': np.zeros((B, T, n, A)), 'u_onehot': np.zeros((B, T, n, A)),
+             'padded': np.ones((B, T, 1)), 'terminated': np.ones((B, T, 1))}
+    for b, ln in enumerate(lens):
+        obs = env.reset()
+        for t in range(ln):
+            acts = [int(np.random.randint(0, A)) for _ in range(n)]
+            nxt, rew, dones, info = env.step(acts)
+            batch['o'][b, t] = np.stack(obs)
+            batch['o_next'][b, t] = np.stack(nxt)
+            batch['u'][b, t, :, 0] = acts
+            batch['u_onehot'][b, t] = np.eye(A)[acts]
+            batch['r'][b, t, 0] = np.sum([rew[k] for k in env.agents]) / n
+            batch['avail_u'][b, t] = 1
+            batch['avail_u_next'][b, t] = 1
+            batch['padded'][b, t] = 0
+            batch['terminated'][b, t] = 1.0 if t == ln - 1 else 0.0
+            obs = nxt
+    assert np.abs(batch['o']).max() < 127 and batch['o'].shape[-1] == O
+    out = {k: (v.astype(np.int8) if k not in ('r',) else v.astype(np.float64)) for k, v in batch.items()}
+    out['padded'] = batch['padded'].astype(np.uint8)
+    out['terminated'] = batch['terminated'].astype(np.uint8)
+    norms = []
+    orig_clip = torch.nn.utils.clip_grad_norm_
+
+    def clip(params, max_norm, *a_, **k_):
+        nn_ = orig_clip(params, max_norm, *a_, **k_)
+        norms.append(float(nn_))
+        return nn_
+    torch.nn.utils.clip_grad_norm_ = clip
+    names = [nm for nm, _ in agents.policy.eval_rnn.named_parameters()]
+    for step in range(2):
+        agents.train({k: v.copy() for k, v in batch.items()}, step)
+        for nm, p in agents.policy.eval_rnn.named_parameters():
+            idx = sample_idx(p.numel())
+            out['idx/%s' % nm] = idx
+            out['grad%d/%s' % (step, nm)] = p.grad.detach().reshape(-1)[idx].numpy().copy()
+            out['w%d/%s' % (step, nm)] = p.detach().reshape(-1)[idx].numpy().copy()
+    torch.nn.utils.clip_grad_norm_ = orig_clip
+    out['grad_norm'] = np.array(norms)
+    out['names'] = np.array(names)
+    out['cfg'] = np.array([W, L, n, fov, a.hyper_hidden_dim, a.grad_norm_clip, A, T])
+    path = os.path.join(OUT, 'vdn_learn_%s.npz' % tag)
+    np.savez_compressed(path, **out)
+    print(os.path.basename(path), 'B=%d grad_norms=%s bytes=%d names=%s' % (B, norms, os.path.getsize(path), names))
+
+
+if __name__ == '__main__' and ('meda' in sys.argv[1:] or not sys.argv[1:]):
+    gen_learn_meda('meda_4d_od32', seed=9)
