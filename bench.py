@@ -263,6 +263,7 @@ def trained_policy_tier(cfg, a, device, rounds):
            'what': 'rollouts only (epsilon-greedy at the trained epsilon, episodes recorded), policy trained for %d rounds of %d chips' % (rounds, E)}
     for name, every in (('skipping_finished_chips', w.compact_every or 4), ('all_rows_every_step', 0)):
         w.compact_every = every
+        w.live_threshold = 2.0   # this tier measures both forms whatever the live share (the default switches at 0.9)
         w._graphs = {}
         for _ in range(2):
             w.generate_episode()
@@ -274,6 +275,7 @@ def trained_policy_tier(cfg, a, device, rounds):
             _, steps, _, success, ep = w.generate_episode()
             played += int((~ep['padded']).sum().item())
             succ += float((success > 0).float().mean().item())
+        out.setdefault('live_share', round(played / float(reps * E * info['episode_limit']), 3))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out[name] = {'env_steps_per_s': round(played / dt, 1), 'rollout_ms': round(dt / reps * 1e3, 3),

@@ -42,9 +42,21 @@ class Evaluator:
         # walk that list (worst-case grids, device-side count: graph-capturable).  Between two compactions the list is a
         # superset of the live chips, which is harmless: a finished chip's rows are computed and ignored, as without the list.
         # The two GRU projections stay full-size library GEMMs.  0 switches it off.
+        # The list costs ~2 % of a lock-step when every chip plays to the end (one more launch every `compact_every` steps, an
+        # indirection in two kernels), so it is used only while episodes do end early: `note_played` keeps the share of
+        # (chip, lock-step) slots that were live in the last round, and the list is on when that share is below `live_threshold`.
         self.compact_every = 4
+        self.live_threshold = 0.9
+        self.live_share = 1.0
         # key of the epsilon-greedy Philox stream: the env seed, shifted per shard so that ranks draw different numbers
         self.rng_seed = (int(getattr(env, 'seed', 0)) * 0x9E3779B97F4A7C15 + int(getattr(env, 'env_id0', 0)) + 0x600) & 0xFFFFFFFFFFFFFFFF
+
+    def note_played(self, played):
+        """env steps played in the round just finished (a host number the caller has anyway) -> share of live slots."""
+        self.live_share = float(played) / float(max(1, self.n_envs * self.episode_limit))
+
+    def _skip_finished(self):
+        return self.compact_every > 0 and self.live_share < self.live_threshold
 
     def _new_round(self, new=False):
         obs = self.reset_fn() if self.reset_fn is not None else self.env.reset(new=new)
@@ -59,7 +71,7 @@ class Evaluator:
     def _play_graphed(self, epsilon, evaluate, record):
         """_play through a captured HIP graph (one graph per (evaluate, record) mode).  epsilon lives in
         a static device tensor that the graph reads and (when annealing) updates in place."""
-        key = (bool(evaluate), bool(record))
+        key = (bool(evaluate), bool(record), self._skip_finished())
         g = self._graphs.get(key)
         if g is None:
             eps_in = torch.zeros((), device=self.device)
@@ -77,10 +89,11 @@ class Evaluator:
                     out = self._play(eps_in, evaluate, record)
             finally:
                 self._capturing = False
-            g = {'graph': graph, 'eps_in': eps_in, 'out': out}
+            g = {'graph': graph, 'eps_in': eps_in, 'out': out, 'last_played': self.last_played}
             self._graphs[key] = g
         g['eps_in'].copy_(torch.as_tensor(epsilon, device=self.device, dtype=torch.float32))
         g['graph'].replay()
+        self.last_played = g['last_played']  # the static tensor of THIS graph (several graphs exist: evaluate / record / live list)
         return g['out']
 
     def _ops(self):
@@ -139,12 +152,12 @@ class Evaluator:
         t_played = 0
         # the GRU input projection runs against rnn.weight_ih zero-padded to K = 640 / 832: one in-place copy per episode
         w_ih_pad = net.refresh_padded() if fused_tail else None
-        live = (fused_tail and self.compact_every > 0 and hasattr(net, 'front_features_live') and net._hip_geometry() == 9
+        live = (fused_tail and self._skip_finished() and hasattr(net, 'front_features_live') and net._hip_geometry() == 9
                 and last_action.dtype == torch.int8)
         if live:
             live_chips = torch.empty(E, dtype=torch.int32, device=dev)
             n_live = torch.zeros(1, dtype=torch.int32, device=dev)
-            x_live = torch.zeros((E * n, net.padded_cols()), dtype=torch.float32, device=dev)  # compact rows; stale rows stay finite
+            x_live = torch.empty((E * n, net.padded_cols()), dtype=torch.float32, device=dev)  # compact rows (rows beyond the live ones: unused)
             if lib.rollout_compact_alive(E, vp(alive.data_ptr()), vp(live_chips.data_ptr()), vp(n_live.data_ptr()), stream) != 0:
                 raise RuntimeError('rollout_compact_alive failed (hip %d)' % lib.rollout_last_hip_error())
         for t in range(T):
@@ -219,6 +232,7 @@ class Evaluator:
         tot = [0.0, 0.0, 0.0, 0.0]
         for _ in range(task_num):
             out = self._generate_episode()
+            self.note_played(int(self.last_played.item()))
             for k in range(4):
                 tot[k] += float(out[k].double().mean().item())
         return tuple(v / task_num for v in tot)

@@ -23,8 +23,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBlockM = 512;
 
 // RBV: rows per workgroup iteration.  0 = the largest block one workgroup per CU can hold (16 rows at od 24, 12 at od 32:
-// 139 / 134 KB of LDS); 8 rows (70 / 89 KB) lets TWO workgroups share a CU at od 24, so one's barriers, prologue gathers and
-// stream-out overlap the other's MFMA phases.
+// 139 / 134 KB of LDS).  Two workgroups per CU (8 rows each) were built twice -- eight waves at 128 registers, and four waves
+// owning both channel halves -- and both measured SLOWER (register spills; tools/probe/conv9_mfma_w4.patch).
 template <int OD, int RBV = 0> struct GeoM {
     static constexpr int RB = RBV ? RBV : (OD <= 24 ? 16 : 12);  // rows per iteration (LDS-bound)
     static constexpr int CS = 53;                        // conv1 activation stride per channel: odd, so the epilogue's
@@ -94,7 +94,7 @@ __device__ __forceinline__ void conv2_tiles(const float *s_a1, float *s_out, con
 }
 
 template <int OD, int RBV = 0>
-__global__ __launch_bounds__(kBlockM, RBV == 0 ? 2 : 4) void k_conv9_mfma(const int8_t *__restrict__ obs, long obs_stride, long rows,
+__global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict__ obs, long obs_stride, long rows,
                                                         const float *__restrict__ w1, const float *__restrict__ b1,
                                                         const float *__restrict__ w2, const float *__restrict__ b2,
                                                         float *__restrict__ out, long out_stride, int out_cols,
@@ -200,28 +200,19 @@ __global__ __launch_bounds__(kBlockM, RBV == 0 ? 2 : 4) void k_conv9_mfma(const 
             // (quarter qt: p = 16 qt + i), position 48 of all RB rows is one more tile.  Wave `sub` takes rows
             // sub, sub + 4, ...: three accumulator chains per row; the gathers of the next row are in flight while
             // the MFMAs of the current one issue.  Addresses are per-lane constants + compile-time offsets.
-            // (RBV != 0: two workgroups per CU, 128 registers per lane: the gathers are not double-buffered -- the other
-            // workgroup's waves cover their latency)
-            constexpr int NB = RBV ? 1 : 2;
-            float cv[NB][3][7];
+            float cv[2][3][7];
 #pragma unroll
             for (int qt = 0; qt < 3; ++qt)
 #pragma unroll
                 for (int s = 0; s < 7; ++s) cv[0][qt][s] = s_in[sub * G::IN_STRIDE + goff[qt] + off1[s]];
 #pragma unroll
             for (int i = 0; i < G::RB / 4; ++i) {
-                if (NB == 1 && i > 0) {
-#pragma unroll
-                    for (int qt = 0; qt < 3; ++qt)
-#pragma unroll
-                        for (int s = 0; s < 7; ++s) cv[0][qt][s] = s_in[(sub + 4 * i) * G::IN_STRIDE + goff[qt] + off1[s]];
-                }
-                if (NB == 2 && i + 1 < G::RB / 4) {
+                if (i + 1 < G::RB / 4) {
 #pragma unroll
                     for (int qt = 0; qt < 3; ++qt)
 #pragma unroll
                         for (int s = 0; s < 7; ++s)
-                            cv[(i + 1) & (NB - 1)][qt][s] = s_in[(sub + 4 * (i + 1)) * G::IN_STRIDE + goff[qt] + off1[s]];
+                            cv[(i + 1) & 1][qt][s] = s_in[(sub + 4 * (i + 1)) * G::IN_STRIDE + goff[qt] + off1[s]];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc[3];
@@ -230,7 +221,7 @@ __global__ __launch_bounds__(kBlockM, RBV == 0 ? 2 : 4) void k_conv9_mfma(const 
 #pragma unroll
                 for (int s = 0; s < 7; ++s)
 #pragma unroll
-                    for (int qt = 0; qt < 3; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i & (NB - 1)][qt][s], bw1[s], acc[qt], 0, 0, 0);
+                    for (int qt = 0; qt < 3; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i & 1][qt][s], bw1[s], acc[qt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (chv) {
                     float *dst = s_a1 + (sub + 4 * i) * G::ROW_A1 + ch * G::CS + kq * 4;
@@ -264,12 +255,8 @@ __global__ __launch_bounds__(kBlockM, RBV == 0 ? 2 : 4) void k_conv9_mfma(const 
 #ifndef CRNN_PROBE_SKIP_CONV2
         {
             int t = sub;
-            if constexpr (RBV == 0) {  // two tiles (two accumulator chains) in flight per wave
-                for (; t + 4 < G::T2; t += 8) conv2_tiles<OD, RBV, 2>(s_a1, s_out, bw2, bias2, t, t + 4, j, kq, ch, chv);
-                if (t < G::T2) conv2_tiles<OD, RBV, 1>(s_a1, s_out, bw2, bias2, t, t, j, kq, ch, chv);
-            } else {
-                for (; t < G::T2; t += 4) conv2_tiles<OD, RBV, 1>(s_a1, s_out, bw2, bias2, t, t, j, kq, ch, chv);
-            }
+            for (; t + 4 < G::T2; t += 8) conv2_tiles<OD, RBV, 2>(s_a1, s_out, bw2, bias2, t, t + 4, j, kq, ch, chv);
+            if (t < G::T2) conv2_tiles<OD, RBV, 1>(s_a1, s_out, bw2, bias2, t, t, j, kq, ch, chv);
         }
 #endif
         if (mlp_w && tid < G::RB * 10) s_out[mr * G::OUT_STRIDE + OD * 25 + mc] = fmaxf(mv, 0.0f);
@@ -294,5 +281,6 @@ __global__ __launch_bounds__(kBlockM, RBV == 0 ? 2 : 4) void k_conv9_mfma(const 
         // next iteration: s_a1 is rewritten after its first barrier, s_out after its second
     }
 }
+
 
 }  // namespace crnn_mfma

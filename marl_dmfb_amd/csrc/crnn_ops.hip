@@ -392,8 +392,6 @@ struct PerDeviceOnce {
     }
 };
 
-constexpr int kConv9DefaultRB24 = 0;  // 0: 16 rows, one workgroup per CU; 8: two workgroups per CU (measured: DESIGN.md section 8)
-
 struct LiveRows { const int32_t *chips; const int32_t *n; int rows_per_chip; };
 
 template <int OD, int RBV>
@@ -420,23 +418,10 @@ int launch_rb(const int8_t *obs, long obs_stride, long rows, const float *w1, co
     return CRNN_OK;
 }
 
-// rows per workgroup iteration: CRNN_CONV9_RB=8|16 (tuning knob); default see conv9_rows_per_block
-static int conv9_rows_per_block(int od) {
-    static int knob = -1;
-    if (knob < 0) { const char *v = getenv("CRNN_CONV9_RB"); knob = v ? atoi(v) : 0; }
-    if (knob == 8 && od == 24) return 8;
-    if (knob == 16 || knob == 12) return 0;
-    return od == 24 ? kConv9DefaultRB24 : 0;
-}
-
 template <int OD>
 int launch(const int8_t *obs, long obs_stride, long rows, const float *w1, const float *b1, const float *w2, const float *b2,
            float *out, long out_stride, int out_cols, const int8_t *onehot, int n_actions, const float *mlp_w, const float *mlp_b, hipStream_t s,
            LiveRows live = LiveRows{nullptr, nullptr, 1}) {
-    if constexpr (OD == 24) {
-        if (conv9_rows_per_block(OD) == 8)
-            return launch_rb<OD, 8>(obs, obs_stride, rows, w1, b1, w2, b2, out, out_stride, out_cols, onehot, n_actions, mlp_w, mlp_b, s, live);
-    }
     return launch_rb<OD, 0>(obs, obs_stride, rows, w1, b1, w2, b2, out, out_stride, out_cols, onehot, n_actions, mlp_w, mlp_b, s, live);
 }
 

@@ -47,6 +47,7 @@ class Trainer:
         """One round of the outer loop (train.py:59-78).  Returns env steps played this round (this rank)."""
         _, steps, _, success, episode = self.rolloutWorker.generate_episode()
         played = int((~episode['padded']).sum().item())
+        self.rolloutWorker.note_played(played)  # decides whether the next rollout keeps finished chips out of the Q-network
         self.buffer.store_episode(episode)
         local = steps.sum()  # failure-inflated count, as train.py:65
         pol = self.agents.policy

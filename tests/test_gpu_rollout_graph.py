@@ -119,6 +119,7 @@ def test_rollout_skipping_finished_chips_equals_the_full_batch_rollout(use_graph
         w = tr.rolloutWorker
         w.reset_fn = env.restart
         w.compact_every = every
+        w.live_share = 0.5          # (as Trainer / evaluate report it after a round with early finishers): the live list is in use
         w.epsilon = torch.tensor(1.0, device='cuda')
         res = []
         for _ in range(2):
