@@ -112,14 +112,19 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
     const int ch = nh * 16 + j;
     const bool chv = ch < OD;
 
-    // ---- B operands: conv1 and conv3 weights of channel ch (forward recompute), and the flipped + transposed conv3 weights
+    // ---- B operands: conv1 and conv3 weights of channel ch (forward recompute), and the flipped + transposed conv3 weights.
+    // Staged through LDS with coalesced loads (151 scattered loads per lane straight from global memory would cost tens of
+    // microseconds per launch: crnn_mfma.h).
+    for (int i = tid; i < OD * OD * 9; i += kBlockB) s_D[i] = w3[i];   // [c_out][c_in][tap]
+    for (int i = tid; i < OD * 27; i += kBlockB) s_B[i] = w1[i];       // [c_out][27]
+    __syncthreads();
     float bw1[7];
     int off1[7];
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
         const int k = 4 * s + kq;
         const bool kv = k < 27;
-        bw1[s] = (chv && kv) ? w1[ch * 27 + k] : 0.0f;
+        bw1[s] = (chv && kv) ? s_B[ch * 27 + k] : 0.0f;
         const int c0 = k / 9, tap = k - c0 * 9;
         off1[s] = kv ? c0 * kFov * kFov + (tap / 3) * kFov + tap % 3 : 0;
     }
@@ -131,9 +136,10 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
     for (int cq = 0; cq < G::KQ; ++cq)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            bw3[cq * 9 + tap] = chv ? w3[((size_t)ch * OD + 4 * cq + kq) * 9 + tap] : 0.0f;           // W[c_out = ch][c_in = 4cq+kq][tap]
-            bwT[cq * 9 + tap] = chv ? w3[((size_t)(4 * cq + kq) * OD + ch) * 9 + (8 - tap)] : 0.0f;   // W[c_out = 4cq+kq][c_in = ch][flipped tap]
+            bw3[cq * 9 + tap] = chv ? s_D[(ch * OD + 4 * cq + kq) * 9 + tap] : 0.0f;           // W[c_out = ch][c_in = 4cq+kq][tap]
+            bwT[cq * 9 + tap] = chv ? s_D[((4 * cq + kq) * OD + ch) * 9 + (8 - tap)] : 0.0f;   // W[c_out = 4cq+kq][c_in = ch][flipped tap]
         }
+    __syncthreads();  // the staging areas are zeroed / reused below
     const float bias1 = chv ? b1[ch] : 0.0f, bias3 = chv ? b3[ch] : 0.0f;
 
     // ---- weight-gradient roles.  dW3: wave w owns column tiles nt = w, w + 8, ... (columns n = 16 nt + j = c_in * 9 + tap) for

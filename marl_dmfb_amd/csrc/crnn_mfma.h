@@ -119,14 +119,19 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
     const int ch = nh * 16 + j;                     // the output channel this lane's B column / D column belongs to
     const bool chv = ch < OD;
 
-    // ---- B operands (weights of channel ch) and the lane's conv1 gather offsets
+    // ---- B operands (weights of channel ch) and the lane's conv1 gather offsets.  The weights go through LDS: read straight
+    // from global memory every lane of a wave hits a different cache line (channel stride 9 od floats), 61 such loads x 8 waves
+    // through the CU's one address unit cost ~15 us per launch; staged with coalesced loads the prologue is ~1 us.
+    for (int i = tid; i < OD * OD * 9; i += kBlockM) s_a1[i] = w2[i];   // [c_out][c_in][tap], s_a1 is free until the first conv1
+    for (int i = tid; i < OD * 27; i += kBlockM) s_in[i] = w1[i];       // [c_out][27]
+    __syncthreads();
     float bw1[7];
     int off1[7];
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
         const int k = 4 * s + kq;
         const bool kv = k < 27;
-        bw1[s] = (chv && kv) ? w1[ch * 27 + k] : 0.0f;
+        bw1[s] = (chv && kv) ? s_in[ch * 27 + k] : 0.0f;
         const int c0 = k / 9, tap = k - c0 * 9;
         off1[s] = kv ? c0 * 81 + (tap / 3) * 9 + tap % 3 : 0;
     }
@@ -137,7 +142,8 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
 #pragma unroll
     for (int cq = 0; cq < G::KQ; ++cq)
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) bw2[cq * 9 + tap] = chv ? w2[((size_t)ch * OD + 4 * cq + kq) * 9 + tap] : 0.0f;
+        for (int tap = 0; tap < 9; ++tap) bw2[cq * 9 + tap] = chv ? s_a1[(ch * OD + 4 * cq + kq) * 9 + tap] : 0.0f;
+    __syncthreads();  // the staging areas are reused below (s_in by park(), s_a1 by conv1)
     const float bias1 = chv ? b1[ch] : 0.0f, bias2 = chv ? b2[ch] : 0.0f;
     const int n_feat = OD * 25 + (mlp_w ? 10 : 0);
     const int n_out = out_cols > n_feat ? out_cols : n_feat;  // columns n_feat .. n_out-1 of a row are written as zeros
@@ -186,12 +192,23 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
         }
         if (mlp_w && tid < G::RB * G::VEC) s_vec[tid] = pfv;
     };
+    // Two barriers per row block.  B2 (after conv1) frees s_in / s_vec: the NEXT block's rows, fetched into registers before conv1,
+    // are parked right behind it, while conv2 runs.  B3 (after conv2) publishes the staged rows and the parked inputs.  There
+    // is NO barrier between a block's stream-out and the next block's conv1: conv1 reads s_in and writes s_a1, the stream-out
+    // reads s_out -- a wave that has streamed its rows out starts on the next conv1 while slower waves still store, and s_out is
+    // rewritten only behind the next B2, which every wave reaches after its stream-out.
     fetch(blockIdx.x);
     park();
+    __syncthreads();
     for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const long row0 = blk * G::RB;
         const int rv = (int)min((long)G::RB, rows - row0);
-        __syncthreads();
+        float mv = 0.0f;  // vector branch: relu(mlp1([dir_x, dir_y, last-action one-hot])) (base_net.py:66); s_vec is re-parked behind B2
+        const int mr = tid / 10, mc = tid - mr * 10;
+        if (mlp_w && tid < G::RB * 10) {
+            mv = mlp_b[mc];
+            for (int k = 0; k < nin; ++k) mv = fmaf(s_vec[mr * G::VEC + k], mlp_w[mc * nin + k], mv);
+        }
         fetch(blk + gridDim.x);
         // ---- conv1
 #ifndef CRNN_PROBE_SKIP_CONV1
@@ -244,13 +261,8 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
             }
         }
 #endif
-        __syncthreads();
-        float mv = 0.0f;  // vector branch: relu(mlp1([dir_x, dir_y, last-action one-hot])) (base_net.py:66)
-        const int mr = tid / 10, mc = tid - mr * 10;
-        if (mlp_w && tid < G::RB * 10) {
-            mv = mlp_b[mc];
-            for (int k = 0; k < nin; ++k) mv = fmaf(s_vec[mr * G::VEC + k], mlp_w[mc * nin + k], mv);
-        }
+        __syncthreads();  // B2
+        park();           // s_in / s_vec were last read before B2
         // ---- conv2
 #ifndef CRNN_PROBE_SKIP_CONV2
         {
@@ -260,8 +272,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
         }
 #endif
         if (mlp_w && tid < G::RB * 10) s_out[mr * G::OUT_STRIDE + OD * 25 + mc] = fmaxf(mv, 0.0f);
-        __syncthreads();
-        park();  // s_in / s_vec were last read before this barrier
+        __syncthreads();  // B3
         // ---- stream the staged rows out: a wave per row, consecutive lanes on consecutive floats
 #ifndef CRNN_PROBE_SKIP_OUT
         if (wide_out) {  // 8-byte stores: n_out, OUT_STRIDE and (checked once) out / out_stride are even
@@ -278,7 +289,6 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
             }
         }
 #endif
-        // next iteration: s_a1 is rewritten after its first barrier, s_out after its second
     }
 }
 

@@ -108,6 +108,7 @@ def test_rollout_skipping_finished_chips_equals_the_full_batch_rollout(use_graph
     starts[:, :, 1] = torch.tensor([1, 4, 7, 8])
     ends = starts.clone()
     off = torch.randint(0, 3, (E, n), generator=rng)        # 0: on the goal, 1 / 2: one cell away in x / y
+    off[:, :3] *= (torch.rand(E, 1, generator=rng) < 0.2).long()   # four chips in five: only the last droplet is off its goal
     ends[:, :, 0] += (off == 1).int()
     ends[:, :, 1] -= (off == 2).int()
     outs = []
