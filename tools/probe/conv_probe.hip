@@ -24,12 +24,12 @@ int main(int argc, char **argv) {
     const int grid = nb < 256 ? nb : 256;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int it = 0; it < 3; ++it)
-        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L,
+        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L, 0,
                            (const int8_t *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 1);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     for (int it = 0; it < 20; ++it)
-        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L,
+        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L, 0,
                            (const int8_t *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 1);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
