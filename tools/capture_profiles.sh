@@ -5,7 +5,7 @@
 # gpurun_out/<round>/summary/ -- copy those into profiles/<round>/ and profiles/traffic.json and commit them.
 # Counter passes are separate runs with --kernel-trace only (gpurun refuses --pmc combined with other trace domains).
 set -eo pipefail
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$ROUND
 SUM=$OUT/summary
@@ -18,19 +18,24 @@ python3 $REPO/bench.py > $SUM/bench.json 2> $OUT/bench.err || { tail -20 $OUT/be
 cat $SUM/bench.json
 
 echo "== bench.py under rocprofv3 --kernel-trace --stats ==" ; date
+# (the persistent k_observe<4> grid is the same at every large batch: this run times ONLY the 655 360-chip roofline launches at it)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 $REPO/bench.py --steps 10 --warmup 3 --no_cpu_baseline \
-    > $SUM/bench_under_rocprof.json 2> $OUT/bench_trace.err
+    --roofline_envs_cached 0 --trained_tier_rounds 0 > $SUM/bench_under_rocprof.json 2> $OUT/bench_trace.err
 python3 $REPO/tools/reduce_profiles.py trace $OUT/bench_trace $SUM/bench_kernels_by_grid.csv
 cp $(ls $OUT/bench_trace/*/*_kernel_stats.csv | head -1) $SUM/bench_kernel_stats.csv
 
 echo "== env tiers (plain) ==" ; date
-python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 --sizes 4096,65536,262144 --iters 100 --observe > $SUM/env_tiers.jsonl
+python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 --sizes 4096,65536,262144,655360 --iters 100 --observe > $SUM/env_tiers.jsonl
 cat $SUM/env_tiers.jsonl
 
 echo "== env kernels under rocprofv3 --kernel-trace ==" ; date
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/env_trace -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 \
     --sizes 4096,262144 --msizes 65536 --iters 40 --observe > $OUT/env_trace.log 2>&1
 python3 $REPO/tools/reduce_profiles.py trace $OUT/env_trace $SUM/env_kernels_by_grid.csv '(dmfbk|medak)::|k_meda_observe'
+# the roofline batch on its own (same persistent grid as 262 144 chips, so a run of its own): A at 655 360 chips
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/env_trace_big -- python3 $REPO/tools/bench_env.py --cfg A --sizes 655360 --iters 40 --observe \
+    > $OUT/env_trace_big.log 2>&1
+python3 $REPO/tools/reduce_profiles.py trace $OUT/env_trace_big $SUM/env_A655360_kernels_by_grid.csv 'dmfbk::'
 
 echo "== HBM traffic counters ==" ; date
 # sizes 4096 + 262144 (MEDA: 65536) only: the fused 4096-chip launch and the 65536-chip step-only launch share a grid size,
@@ -40,6 +45,17 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 \
     --sizes 4096,262144 --msizes 65536 --iters 24 --observe > $OUT/pmc_write.log 2>&1
 python3 $REPO/tools/reduce_profiles.py traffic $OUT/pmc_fetch $OUT/pmc_write $SUM/traffic.json $OUT/labels.json
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_big -- python3 $REPO/tools/bench_env.py --cfg A --sizes 655360 --iters 24 --observe \
+    --labels $OUT/labels_big.json > $OUT/pmc_fetch_big.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_big -- python3 $REPO/tools/bench_env.py --cfg A --sizes 655360 --iters 24 --observe \
+    > $OUT/pmc_write_big.log 2>&1
+python3 $REPO/tools/reduce_profiles.py traffic $OUT/pmc_fetch_big $OUT/pmc_write_big $OUT/traffic_big.json $OUT/labels_big.json
+python3 - <<PY
+import json
+a = json.load(open('$SUM/traffic.json')); b = json.load(open('$OUT/traffic_big.json'))
+a['detail'] += b.pop('detail'); b.pop('note', None); a.update(b)
+json.dump(a, open('$SUM/traffic.json', 'w'), indent=1)
+PY
 echo "== write-pattern and counter-calibration probes ==" ; date
 make -C $REPO/tools/probe -s bin/write_probe bin/fetch_calib || true   # built from source, never a checked-in binary
 if [ -x $REPO/tools/probe/bin/write_probe ]; then
