@@ -76,7 +76,7 @@ def parse(argv=None):
                     help='chips per launch of the roofline kernel: 655 360 x 980 B = 642 MB of output, 2.5x the 256 MiB Infinity Cache')
     ap.add_argument('--roofline_envs_cached', type=int, default=262144,
                     help='second, cache-assisted batch (257 MB of output) reported as tiers.fov_kernel_cache_resident')
-    ap.add_argument('--trained_tier_rounds', type=int, default=300,
+    ap.add_argument('--trained_tier_rounds', type=int, default=500,
                     help='rounds of training before the env+policy tier with a trained policy is measured (0: skip that tier)')
     ap.add_argument('--launch_check', action='store_true',
                     help='rendezvous + collectives only (no GPU work): checks the --gpus N launch plumbing')
@@ -261,25 +261,28 @@ def trained_policy_tier(cfg, a, device, rounds):
     w = tr.rolloutWorker
     out = {'trained_rounds': rounds, 'train_seconds': round(t_train, 2), 'epsilon': round(float(w.epsilon), 4),
            'what': 'rollouts only (epsilon-greedy at the trained epsilon, episodes recorded), policy trained for %d rounds of %d chips' % (rounds, E)}
-    for name, every in (('skipping_finished_chips', w.compact_every or 4), ('all_rows_every_step', 0)):
-        w.compact_every = every
-        w.live_threshold = 2.0   # this tier measures both forms whatever the live share (the default switches at 0.9)
-        w._graphs = {}
-        for _ in range(2):
-            w.generate_episode()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        played, n_ep, succ = 0, 0, 0.0
-        reps = 6
-        for _ in range(reps):
-            _, steps, _, success, ep = w.generate_episode()
-            played += int((~ep['padded']).sum().item())
-            succ += float((success > 0).float().mean().item())
-        out.setdefault('live_share', round(played / float(reps * E * info['episode_limit']), 3))
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out[name] = {'env_steps_per_s': round(played / dt, 1), 'rollout_ms': round(dt / reps * 1e3, 3),
-                     'mean_steps_per_episode': round(played / (reps * E), 2), 'success_rate': round(succ / reps, 3)}
+    w.live_threshold = 2.0   # this tier measures both forms whatever the live share (the default switches at 0.75)
+    forms = (('skipping_finished_chips', w.compact_every or 4), ('all_rows_every_step', 0))
+    reps = 6
+    for rnd in range(2):     # A B A B: each form keeps its faster pass (clocks and caches drift for seconds after the training burst)
+        for name, every in forms:
+            w.compact_every = every          # (the captured graphs are keyed by the form in use)
+            for _ in range(2):
+                w.generate_episode()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            played, succ = 0, 0.0
+            for _ in range(reps):
+                _, steps, _, success, ep = w.generate_episode()
+                played += int((~ep['padded']).sum().item())
+                succ += float((success > 0).float().mean().item())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            rec = {'env_steps_per_s': round(played / dt, 1), 'rollout_ms': round(dt / reps * 1e3, 3),
+                   'mean_steps_per_episode': round(played / (reps * E), 2), 'success_rate': round(succ / reps, 3)}
+            if name not in out or rec['rollout_ms'] < out[name]['rollout_ms']:
+                out[name] = rec
+            out['live_share'] = round(played / float(reps * E * info['episode_limit']), 3)
     env.close()
     return out
 
@@ -316,7 +319,7 @@ def conv_front_roofline(net, n, fov, rows_list, device):
         tf = R * flop_row / us / 1e6
         shapes.append({'rows_per_launch': R, 'avg_launch_us': round(us, 2), 'achieved': round(tf, 2), 'frac': round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
     top = shapes[0]
-    return {'bound': 'mfma', 'kernel': 'crnn_mfma::k_conv9_mfma<%d>' % od, 'achieved': top['achieved'], 'peak': FP32_MFMA_PEAK_TFLOPS,
+    return {'bound': 'mfma', 'kernel': 'crnn_mfma::k_conv9_mfma<%d, 0>' % od, 'achieved': top['achieved'], 'peak': FP32_MFMA_PEAK_TFLOPS,
             'unit': 'TFLOP/s', 'frac': top['frac'], 'dtype': 'fp32 operands and accumulation (v_mfma_f32_16x16x4_f32)',
             'rows_per_launch': top['rows_per_launch'], 'avg_launch_us': top['avg_launch_us'], 'useful_flop_per_row': flop_row,
             'other_launch_shapes': shapes[1:],

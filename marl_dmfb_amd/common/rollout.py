@@ -44,9 +44,9 @@ class Evaluator:
         # The two GRU projections stay full-size library GEMMs.  0 switches it off.
         # The list costs ~2 % of a lock-step when every chip plays to the end (one more launch every `compact_every` steps, an
         # indirection in two kernels), so it is used only while episodes do end early: `note_played` keeps the share of
-        # (chip, lock-step) slots that were live in the last round, and the list is on when that share is below `live_threshold`.
+        # (chip, lock-step) slots that were live in the last round, and the list is on when that share is below `live_threshold` (break-even measured near 0.75: tools/bench_front_live.py).
         self.compact_every = 4
-        self.live_threshold = 0.9
+        self.live_threshold = 0.75
         self.live_share = 1.0
         # key of the epsilon-greedy Philox stream: the env seed, shifted per shard so that ranks draw different numbers
         self.rng_seed = (int(getattr(env, 'seed', 0)) * 0x9E3779B97F4A7C15 + int(getattr(env, 'env_id0', 0)) + 0x600) & 0xFFFFFFFFFFFFFFFF
