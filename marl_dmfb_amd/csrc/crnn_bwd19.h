@@ -14,7 +14,10 @@
 // tiles whose accumulators stay in registers over ALL row blocks of the workgroup; the workgroup writes ONE partial vector at the
 // end and a second kernel adds the <= 256 partial vectors in a fixed order (deterministic, no atomics).
 // LDS per row: image bytes, a1 (9x9), a2 (7x7), a 9x9 plane set (dz3 padded, later dz1) and an 11x11 plane set (dz2 padded):
-// 45.6 KB at od 32 (3 rows per workgroup), 34.5 KB at od 24 (4 rows).
+// 45.6 KB at od 32 (2 rows per workgroup), 34.5 KB at od 24 (4 rows); next to them the conv3 weights stay in LDS for the whole
+// launch (37 KB at od 32).  A lane's 72 B operands of a conv3-shaped pass are re-read from there at the head of the pass (the
+// forward's set before S2, the flipped + transposed set before D2): holding both sets in registers next to the dW3
+// accumulators cost 98 spilled registers per lane and a scratch load in front of most matrix instructions.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,18 +33,22 @@ using crnn_mfma19::kPix;
 constexpr int kBlockB = 512;
 
 template <int OD> struct GeoB19 {
-    static constexpr int RBB = OD <= 24 ? 4 : 3;          // rows per iteration (LDS-bound)
+    static constexpr int RBB = OD <= 24 ? 4 : 2;          // rows per iteration (LDS-bound)
     static constexpr int IMG = 1088;                       // staged pixel bytes per row
     static constexpr int CS1 = 85, CS2 = 53, CS4 = 125;    // channel strides of 9x9, 7x7 and 11x11 planes (odd: bank spread)
     static constexpr int ROW_A = OD * CS1, ROW_B = OD * CS2, ROW_C = OD * CS1, ROW_D = OD * CS4;
     static constexpr int KQ = OD / 4, NSTEP = KQ * 9;
     static constexpr int NCOL3 = OD * 9, NT3 = (NCOL3 + 15) / 16;  // dW3 columns (c_in, tap) and their 16-wide tiles
-    static constexpr int NTW = (NT3 + 7) / 8;              // dW3 column tiles per wave (8 waves)
+    static constexpr int NTW = (NT3 + 3) / 4;              // dW3 column tiles per wave (a wave owns ONE 16-row half of c_out)
+    static constexpr int WS = OD * 9 + 1;                  // c_out stride of the LDS copy of W3 (odd: the 16 channels of a wave hit 16 banks)
+    static constexpr int W_FLOATS = OD * WS;
+    static constexpr int PFR = (OD * 25 + kBlockB - 1) / kBlockB;       // prefetched (a3, g) pairs per thread and row
+    static constexpr int PFI = (kPix + kBlockB - 1) / kBlockB;         // prefetched image bytes per thread and row
     static constexpr int N_W3 = OD * OD * 9, N_W1 = OD * 27;
     // partial vector of a workgroup: dW3 | dW1 | bias sums per thread: [kBlockB] dz3+dz2, [kBlockB] dz1
     static constexpr int PART = N_W3 + N_W1 + 2 * kBlockB;
     static constexpr int GRADS = N_W3 + OD + N_W1 + OD;   // dW3 | db3 | dW1 | db1
-    static constexpr size_t LDS_FLOATS = (size_t)RBB * (IMG / 4 + ROW_A + ROW_B + ROW_C + ROW_D);
+    static constexpr size_t LDS_FLOATS = (size_t)RBB * (IMG / 4 + ROW_A + ROW_B + ROW_C + ROW_D) + W_FLOATS;
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "one workgroup per CU");
     static_assert(OD * 16 <= kBlockB, "bias sums: one thread per (channel, 1/16 of the positions)");
 };
@@ -106,16 +113,17 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
     float *s_B = s_A + G::RBB * G::ROW_A;                    // [RBB][OD][53]  a2 (7x7)
     float *s_C = s_B + G::RBB * G::ROW_B;                    // [RBB][OD][85]  dz3 zero-padded to 9x9, later dz1 (9x9)
     float *s_D = s_C + G::RBB * G::ROW_C;                    // [RBB][OD][125] dz2 zero-padded to 11x11
+    float *s_W = s_D + G::RBB * G::ROW_D;                    // [OD][WS]       conv3 weights [c_out][c_in][tap], c_out stride WS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nh = (wave >> 1) & 1, sub = (wave & 1) + 2 * (wave >> 2);
     const int j = lane & 15, kq = lane >> 4;
     const int ch = nh * 16 + j;
     const bool chv = ch < OD;
+    const int chc = chv ? ch : 0;
 
-    // ---- B operands: conv1 and conv3 weights of channel ch (forward recompute), and the flipped + transposed conv3 weights.
-    // Staged through LDS with coalesced loads (151 scattered loads per lane straight from global memory would cost tens of
-    // microseconds per launch: crnn_mfma.h).
-    for (int i = tid; i < OD * OD * 9; i += kBlockB) s_D[i] = w3[i];   // [c_out][c_in][tap]
+    // ---- weights into LDS with coalesced loads (scattered per-lane loads straight from global memory cost tens of microseconds
+    // per launch: crnn_mfma.h); conv1's 7 B operands per lane stay in registers.
+    for (int i = tid; i < OD * OD * 9; i += kBlockB) { const int co = i / (OD * 9); s_W[co * G::WS + (i - co * OD * 9)] = w3[i]; }
     for (int i = tid; i < OD * 27; i += kBlockB) s_B[i] = w1[i];       // [c_out][27]
     __syncthreads();
     float bw1[7];
@@ -131,34 +139,33 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
     int goff[5];
 #pragma unroll
     for (int qt = 0; qt < 5; ++qt) { const int p = qt * 16 + j; goff[qt] = 2 * (p / 9) * kFov + 2 * (p % 9); }
-    float bw3[G::NSTEP], bwT[G::NSTEP];
-#pragma unroll
-    for (int cq = 0; cq < G::KQ; ++cq)
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            bw3[cq * 9 + tap] = chv ? s_D[(ch * OD + 4 * cq + kq) * 9 + tap] : 0.0f;           // W[c_out = ch][c_in = 4cq+kq][tap]
-            bwT[cq * 9 + tap] = chv ? s_D[((4 * cq + kq) * OD + ch) * 9 + (8 - tap)] : 0.0f;   // W[c_out = 4cq+kq][c_in = ch][flipped tap]
-        }
-    __syncthreads();  // the staging areas are zeroed / reused below
+    __syncthreads();  // the staging area is zeroed / reused below
     const float bias1 = chv ? b1[ch] : 0.0f, bias3 = chv ? b3[ch] : 0.0f;
+    const float *wf = s_W + chc * G::WS + kq * 9;             // forward set:  W[c_out = ch][c_in = 4cq+kq][tap]         at wf[36 cq + tap]
+    const float *wt = s_W + kq * G::WS + chc * 9 + 8;         // backward set: W[c_out = 4cq+kq][c_in = ch][8 - tap]     at wt[4 WS cq - tap]
+    float bw[G::NSTEP];
 
-    // ---- weight-gradient roles.  dW3: wave w owns column tiles nt = w, w + 8, ... (columns n = 16 nt + j = c_in * 9 + tap) for
-    // both 16-row halves of c_out.  dW1: waves 0..3 own tile (half = w & 1, column tile = w >> 1) of the 27 (c0, tap) columns.
-    f32x4 acc3[G::NTW][2];
+    // ---- weight-gradient roles.  dW3: wave w owns the 16-row half (w & 1) of c_out for column tiles nt = (w >> 1), (w >> 1) + 4,
+    // ... (columns n = 16 nt + j = c_in * 9 + tap).  dW1: waves 0..3 own tile (half = w & 1, column tile = w >> 1) of the 27
+    // (c0, tap) columns.
+    const int wh = wave & 1, wt0 = wave >> 1;
+    const int a_ch = 16 * wh + j;
+    const bool a_chv = a_ch < OD;
+    const int a_chc = a_chv ? a_ch : 0;
+    f32x4 acc3[G::NTW];
     int colB_a2[G::NTW], colB_a1[G::NTW];   // per-lane offset of column n inside a row's a2 / a1 planes (channel + tap shift)
     bool colv[G::NTW];
 #pragma unroll
     for (int u = 0; u < G::NTW; ++u) {
-        const int n = 16 * (wave + 8 * u) + j;
-        colv[u] = wave + 8 * u < G::NT3 && n < G::NCOL3;
+        const int n = 16 * (wt0 + 4 * u) + j;
+        colv[u] = wt0 + 4 * u < G::NT3 && n < G::NCOL3;
         const int ci = colv[u] ? n / 9 : 0, tap = colv[u] ? n % 9 : 0;
         colB_a2[u] = ci * G::CS2 + (tap / 3) * 7 + tap % 3;
         colB_a1[u] = ci * G::CS1 + (tap / 3) * 9 + tap % 3;
-        acc3[u][0] = f32x4{0, 0, 0, 0};
-        acc3[u][1] = f32x4{0, 0, 0, 0};
+        acc3[u] = f32x4{0, 0, 0, 0};
     }
     f32x4 acc1 = {0, 0, 0, 0};
-    const int w1_half = wave & 1, w1_n = 16 * (wave >> 1) + j;
+    const int w1_n = 16 * wt0 + j;
     const bool w1_on = wave < 4, w1_colv = w1_on && w1_n < 27;
     const int w1_off = w1_colv ? (w1_n / 9) * kFov * kFov + ((w1_n % 9) / 3) * kFov + (w1_n % 9) % 3 : 0;
     float accb3 = 0.0f, accb1 = 0.0f;        // bias sums: thread = (channel tid % OD, position slice tid / OD), tid < 16 OD
@@ -168,38 +175,70 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
     for (int i = tid; i < G::RBB * (G::ROW_C + G::ROW_D); i += kBlockB) s_C[i] = 0.0f;  // the zero borders of the padded planes (s_D follows s_C)
     for (int i = tid; i < G::RBB * G::IMG / 4; i += kBlockB) ((int *)s_img)[i] = 0;
 
+    // ---- the row block's inputs travel one iteration ahead in registers: dz3's two sources (a3, g) of the 5x5 interior and the
+    // image bytes.  Slot s of a thread is element tid + s * kBlockB of [RBB][OD][25] resp. [RBB][361].
+    float pf_a[G::RBB][G::PFR], pf_g[G::RBB][G::PFR];
+    int8_t pf_i[G::RBB][G::PFI];
+    int pf_dst[G::PFR];                       // where feature tid + h * kBlockB of a row lands in its padded planes
+#pragma unroll
+    for (int h = 0; h < G::PFR; ++h) {
+        const int f = tid + h * kBlockB, c = f / 25, q = f - c * 25;
+        pf_dst[h] = f < OD * 25 ? c * G::CS1 + (q / 5 + 2) * 9 + q % 5 + 2 : -1;
+    }
+    auto prefetch = [&](long row0, int rv) {
+#pragma unroll
+        for (int rr = 0; rr < G::RBB; ++rr) {
+            const bool on = rr < rv;
+            const float *pa = a3 + (row0 + rr) * a3_stride + tid, *pg = g + (row0 + rr) * g_stride + tid;
+#pragma unroll
+            for (int h = 0; h < G::PFR; ++h) {
+                const bool in = on && pf_dst[h] >= 0;
+                pf_a[rr][h] = in ? pa[h * kBlockB] : 0.0f;
+                pf_g[rr][h] = in ? pg[h * kBlockB] : 0.0f;
+            }
+#pragma unroll
+            for (int h = 0; h < G::PFI; ++h)
+                pf_i[rr][h] = (on && tid + h * kBlockB < kPix) ? obs[(row0 + rr) * obs_stride + tid + h * kBlockB] : (int8_t)0;
+        }
+    };
+
     const long n_blocks = (rows + G::RBB - 1) / G::RBB;
     const long per = (n_blocks + gridDim.x - 1) / gridDim.x;
     const long blk0 = (long)blockIdx.x * per, blk1 = min(n_blocks, blk0 + per);
+    if (blk0 < blk1) prefetch(blk0 * G::RBB, (int)min((long)G::RBB, rows - blk0 * G::RBB));
     for (long blk = blk0; blk < blk1; ++blk) {
-        const long row0 = blk * G::RBB;
-        const int rv = (int)min((long)G::RBB, rows - row0);
         __syncthreads();  // the previous block's phases are done with every buffer
-        // ---- stage in: image bytes, and dz3 = g * (a3 > 0) into the interior of the zeroed 9x9 planes (border rewritten: the
+        // ---- stage in: image bytes, and dz3 = g * (a3 > 0) into the interior of the 9x9 planes; the border is zeroed again (the
         // planes held dz1 of the previous block)
-        for (int i = tid; i < G::RBB * kPix; i += kBlockB) {
-            const int rr = i / kPix, p = i - rr * kPix;
-            s_img[rr * G::IMG + p] = rr < rv ? obs[(row0 + rr) * obs_stride + p] : (int8_t)0;
+#pragma unroll
+        for (int rr = 0; rr < G::RBB; ++rr)
+#pragma unroll
+            for (int h = 0; h < G::PFI; ++h)
+                if (tid + h * kBlockB < kPix) s_img[rr * G::IMG + tid + h * kBlockB] = pf_i[rr][h];
+#pragma unroll 1
+        for (int i = tid; i < G::RBB * OD * 56; i += kBlockB) {   // 56 border cells of a 9x9 plane around its 5x5 interior
+            const int pl = i / 56, b = i - pl * 56;
+            // b < 18: rows 0, 1;  b < 36: rows 7, 8;  else rows 2..6, columns 0, 1, 7, 8
+            const int p = b < 18 ? b : b < 36 ? 45 + b : (2 + (b - 36) / 4) * 9 + ((b - 36) % 4 < 2 ? (b - 36) % 4 : (b - 36) % 4 + 5);
+            const int rr = pl / OD, c = pl - rr * OD;
+            s_C[rr * G::ROW_C + c * G::CS1 + p] = 0.0f;
         }
-        for (int i = tid; i < G::RBB * OD * 81; i += kBlockB) {
-            const int rr = i / (OD * 81), rem = i - rr * OD * 81, c = rem / 81, p = rem - c * 81;
-            const int y = p / 9 - 2, x = p % 9 - 2;
-            float v = 0.0f;
-            if (rr < rv && y >= 0 && y < 5 && x >= 0 && x < 5) {
-                const int f = c * 25 + y * 5 + x;
-                v = a3[(row0 + rr) * a3_stride + f] > 0.0f ? g[(row0 + rr) * g_stride + f] : 0.0f;
-            }
-            s_C[rr * G::ROW_C + c * G::CS1 + p] = v;
-        }
+#pragma unroll
+        for (int rr = 0; rr < G::RBB; ++rr)
+#pragma unroll
+            for (int h = 0; h < G::PFR; ++h)
+                if (pf_dst[h] >= 0) s_C[rr * G::ROW_C + pf_dst[h]] = pf_a[rr][h] > 0.0f ? pf_g[rr][h] : 0.0f;
+        if (blk + 1 < blk1) prefetch((blk + 1) * G::RBB, (int)min((long)G::RBB, rows - (blk + 1) * G::RBB));
         __syncthreads();
         // ---- S1: a1 = relu(conv1(img)), the forward's stage 1 (rows split over the four waves of a channel half)
+#pragma unroll 1
         for (int rr = sub; rr < G::RBB; rr += 4) {
             const int8_t *img = s_img + rr * G::IMG;
             float *dst = s_A + rr * G::ROW_A + ch * G::CS1 + kq * 4;
             crnn_mfma19::stage1_tiles<0, 3>(img, dst, goff, off1, bw1, bias1, chv);
             crnn_mfma19::stage1_tiles<3, 2>(img, dst, goff, off1, bw1, bias1, chv);
         }
-        if (sub == 0) {  // position 80 of every row: lane i gathers row i
+        if (sub == (G::RBB < 4 ? 3 : 0)) {  // position 80 of every row: lane i gathers row i
             const int rr = j < G::RBB ? j : G::RBB - 1;
             f32x4 acc = {bias1, bias1, bias1, bias1};
 #pragma unroll
@@ -211,21 +250,31 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
                     if (kq * 4 + q < G::RBB) s_A[(kq * 4 + q) * G::ROW_A + ch * G::CS1 + 80] = fmaxf(acc[q], 0.0f);
             }
         }
+#pragma unroll
+        for (int cq = 0; cq < G::KQ; ++cq)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) { const float w = wf[36 * cq + tap]; bw[cq * 9 + tap] = chv ? w : 0.0f; }
         __syncthreads();
         // ---- S2: a2 = relu(conv3(a1))
         {
             constexpr int M2 = G::RBB * 49, T2 = (M2 + 15) / 16;
+#pragma unroll 1
             for (int t = sub; t < T2; t += 4)
-                conv_tiles<OD, 1, 9, 7, G::CS1, G::ROW_A, M2>(s_A, bw3, bias3, t, t, j, kq, [&](int mm, float v) {
+                conv_tiles<OD, 1, 9, 7, G::CS1, G::ROW_A, M2>(s_A, bw, bias3, t, t, j, kq, [&](int mm, float v) {
                     if (chv) { const int rr = mm / 49, pp = mm - rr * 49; s_B[rr * G::ROW_B + ch * G::CS2 + pp] = fmaxf(v, 0.0f); }
                 });
         }
+#pragma unroll
+        for (int cq = 0; cq < G::KQ; ++cq)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) { const float w = wt[4 * G::WS * cq - tap]; bw[cq * 9 + tap] = chv ? w : 0.0f; }
         __syncthreads();
         // ---- D2: dz2 = convT(dz3) * (a2 > 0) into the interior of the 11x11 planes;  W3a: dW3 += dz3 (x) a2;  db3 += sum dz3
         {
             constexpr int M2 = G::RBB * 49, T2 = (M2 + 15) / 16;
+#pragma unroll 1
             for (int t = sub; t < T2; t += 4)
-                conv_tiles<OD, 1, 9, 7, G::CS1, G::ROW_C, M2>(s_C, bwT, 0.0f, t, t, j, kq, [&](int mm, float v) {
+                conv_tiles<OD, 1, 9, 7, G::CS1, G::ROW_C, M2>(s_C, bw, 0.0f, t, t, j, kq, [&](int mm, float v) {
                     if (chv) {
                         const int rr = mm / 49, pp = mm - rr * 49;
                         const float act = s_B[rr * G::ROW_B + ch * G::CS2 + pp];
@@ -233,21 +282,24 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
                     }
                 });
             constexpr int K3 = G::RBB * 25;
+#pragma unroll 1
             for (int k0 = 0; k0 < K3; k0 += 4) {
                 const int k = k0 + kq;
                 const bool kv = k < K3;
                 const int rr = kv ? k / 25 : 0, p = kv ? k - rr * 25 : 0;
                 const float *za = s_C + rr * G::ROW_C + (p / 5 + 2) * 9 + p % 5 + 2;       // dz3[rr][.][p] in its padded plane
                 const float *zb = s_B + rr * G::ROW_B + (p / 5) * 7 + p % 5;                 // a2 window origin of position p
-                const float a_lo = kv ? za[j * G::CS1] : 0.0f, a_hi = (kv && 16 + j < OD) ? za[(16 + j) * G::CS1] : 0.0f;
+                const float a_raw = za[a_chc * G::CS1];
+                const float av = (kv && a_chv) ? a_raw : 0.0f;
 #pragma unroll
-                for (int u = 0; u < G::NTW; ++u) {
-                    const float bv = colv[u] ? zb[colB_a2[u]] : 0.0f;
-                    acc3[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo, bv, acc3[u][0], 0, 0, 0);
-                    acc3[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi, bv, acc3[u][1], 0, 0, 0);
-                }
+                for (int u = 0; u < G::NTW; ++u)
+                    if (wt0 + 4 * u < G::NT3) {
+                        const float b_raw = zb[colB_a2[u]];
+                        acc3[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, colv[u] ? b_raw : 0.0f, acc3[u], 0, 0, 0);
+                    }
             }
             if (b_on)
+#pragma unroll 1
                 for (int q = bs; q < G::RBB * 25; q += 16) {
                     const int rr = q / 25, p = q - rr * 25;
                     accb3 += s_C[rr * G::ROW_C + bc * G::CS1 + (p / 5 + 2) * 9 + p % 5 + 2];
@@ -257,8 +309,9 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
         // ---- D1: dz1 = convT(dz2) * (a1 > 0) into the 9x9 planes (dz3 is dead);  W3b: dW3 += dz2 (x) a1;  db3 += sum dz2
         {
             constexpr int M1 = G::RBB * 81, T1 = (M1 + 15) / 16;
+#pragma unroll 1
             for (int t = sub; t < T1; t += 4)
-                conv_tiles<OD, 1, 11, 9, G::CS4, G::ROW_D, M1>(s_D, bwT, 0.0f, t, t, j, kq, [&](int mm, float v) {
+                conv_tiles<OD, 1, 11, 9, G::CS4, G::ROW_D, M1>(s_D, bw, 0.0f, t, t, j, kq, [&](int mm, float v) {
                     if (chv) {
                         const int rr = mm / 81, pp = mm - rr * 81;
                         const float act = s_A[rr * G::ROW_A + ch * G::CS1 + pp];
@@ -266,21 +319,24 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
                     }
                 });
             constexpr int K2 = G::RBB * 49;
+#pragma unroll 1
             for (int k0 = 0; k0 < K2; k0 += 4) {
                 const int k = k0 + kq;
                 const bool kv = k < K2;
                 const int rr = kv ? k / 49 : 0, p = kv ? k - rr * 49 : 0;
                 const float *za = s_D + rr * G::ROW_D + (p / 7 + 2) * 11 + p % 7 + 2;
                 const float *zb = s_A + rr * G::ROW_A + (p / 7) * 9 + p % 7;
-                const float a_lo = kv ? za[j * G::CS4] : 0.0f, a_hi = (kv && 16 + j < OD) ? za[(16 + j) * G::CS4] : 0.0f;
+                const float a_raw = za[a_chc * G::CS4];
+                const float av = (kv && a_chv) ? a_raw : 0.0f;
 #pragma unroll
-                for (int u = 0; u < G::NTW; ++u) {
-                    const float bv = colv[u] ? zb[colB_a1[u]] : 0.0f;
-                    acc3[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo, bv, acc3[u][0], 0, 0, 0);
-                    acc3[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi, bv, acc3[u][1], 0, 0, 0);
-                }
+                for (int u = 0; u < G::NTW; ++u)
+                    if (wt0 + 4 * u < G::NT3) {
+                        const float b_raw = zb[colB_a1[u]];
+                        acc3[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, colv[u] ? b_raw : 0.0f, acc3[u], 0, 0, 0);
+                    }
             }
             if (b_on)
+#pragma unroll 1
                 for (int q = bs; q < G::RBB * 49; q += 16) {
                     const int rr = q / 49, p = q - rr * 49;
                     accb3 += s_D[rr * G::ROW_D + bc * G::CS4 + (p / 7 + 2) * 11 + p % 7 + 2];
@@ -290,17 +346,18 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
         // ---- W1: dW1 += dz1 (x) stride-2 image windows;  db1 += sum dz1
         if (w1_on) {
             constexpr int K1 = G::RBB * 81;
+#pragma unroll 1
             for (int k0 = 0; k0 < K1; k0 += 4) {
                 const int k = k0 + kq;
                 const bool kv = k < K1;
                 const int rr = kv ? k / 81 : 0, p = kv ? k - rr * 81 : 0;
-                const int cc = 16 * w1_half + j;
-                const float av = (kv && cc < OD) ? s_C[rr * G::ROW_C + cc * G::CS1 + p] : 0.0f;
+                const float av = (kv && a_chv) ? s_C[rr * G::ROW_C + a_chc * G::CS1 + p] : 0.0f;
                 const float bv = w1_colv ? (float)s_img[rr * G::IMG + 2 * (p / 9) * kFov + 2 * (p % 9) + w1_off] : 0.0f;
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc1, 0, 0, 0);
             }
         }
         if (b_on)
+#pragma unroll 1
             for (int q = bs; q < G::RBB * 81; q += 16) {
                 const int rr = q / 81, p = q - rr * 81;
                 accb1 += s_C[rr * G::ROW_C + bc * G::CS1 + p];
@@ -311,16 +368,14 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
 #pragma unroll
     for (int u = 0; u < G::NTW; ++u)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co = 16 * h + 4 * kq + q, n = 16 * (wave + 8 * u) + j;
-                if (colv[u] && co < OD) mine[(size_t)co * G::NCOL3 + n] = acc3[u][h][q];  // (c_out * OD + c_in) * 9 + tap = c_out * 9 OD + n
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int co = 16 * wh + 4 * kq + q, n = 16 * (wt0 + 4 * u) + j;
+            if (colv[u] && co < OD) mine[(size_t)co * G::NCOL3 + n] = acc3[u][q];  // (c_out * OD + c_in) * 9 + tap = c_out * 9 OD + n
+        }
     if (w1_on) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int c1 = 16 * w1_half + 4 * kq + q;
+            const int c1 = 16 * wh + 4 * kq + q;
             if (w1_colv && c1 < OD) mine[G::N_W3 + c1 * 27 + w1_n] = acc1[q];
         }
     }

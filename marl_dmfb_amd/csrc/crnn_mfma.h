@@ -40,8 +40,8 @@ template <int OD, int RBV = 0> struct GeoM {
     static constexpr int T2 = (M2 + 15) / 16;
     static_assert(RB % 4 == 0 && RB <= 16, "conv1 tiling: rows split over 4 waves per half, one position-48 tile");
     static constexpr int VEC = 18;                       // dir_x, dir_y, one-hot (<= 16) per row
-    static constexpr int NPF = (RB * 243 + kBlockM - 1) / kBlockM;  // pixel bytes prefetched per thread
-    static constexpr size_t LDS_FLOATS = (size_t)RB * IN_STRIDE + (size_t)RB * ROW_A1 + (size_t)RB * OUT_STRIDE + (size_t)RB * VEC;
+    static constexpr int MLP = 10 * VEC + 10;            // the vector branch's weights [10][nin] and biases
+    static constexpr size_t LDS_FLOATS = (size_t)RB * IN_STRIDE + (size_t)RB * ROW_A1 + (size_t)RB * OUT_STRIDE + (size_t)RB * VEC + MLP;
 };
 
 // conv2 for NT (1 or 2) tiles of 16 output positions: gathers of channel quad cq + 1 are issued before the MFMAs of
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
     float *s_a1 = s_in + G::RB * G::IN_STRIDE;      // [RB][OD][53] conv1 activations
     float *s_out = s_a1 + G::RB * G::ROW_A1;        // [RB][OUT_STRIDE]
     float *s_vec = s_out + G::RB * G::OUT_STRIDE;   // [RB][18] inputs of the vector branch
+    float *s_mlp = s_vec + G::RB * G::VEC;          // [10][nin] weights, then [10] biases of the vector branch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // wave w runs on SIMD w & 3: SIMDs 0,1 hold channel half 0, SIMDs 2,3 half 1; the two waves of a SIMD take
     // tiles sub, sub + 4, ... with sub = (w & 1) and (w & 1) + 2, so every SIMD gets 12 or 13 of the 25 conv2 tiles
@@ -156,6 +157,12 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
     if (live_chips) rows = min(rows, (long)n_live[0] * rows_per_chip);
     const long n_blocks = (rows + G::RB - 1) / G::RB;
     const int nin = 2 + n_actions;
+    // the vector branch's parameters live in LDS: read from global memory at the head of every row block, the wait for them
+    // was also a wait for the previous block's output stores (one in-order memory counter on gfx9)
+    if (mlp_w) {
+        for (int i = tid; i < 10 * nin; i += kBlockM) s_mlp[i] = mlp_w[i];
+        if (tid < 10) s_mlp[10 * G::VEC + tid] = mlp_b[tid];
+    }
     // cr / rows_per_chip as a multiply-high (exact for cr * rows_per_chip < 2^32: the host checks the row count)
     const uint32_t rpc_magic = (uint32_t)(0x100000000ull / (uint32_t)(rows_per_chip > 0 ? rows_per_chip : 1)) + 1u;
     auto src_row = [&](long cr) -> long {  // compact row -> row of the input tensors
@@ -164,33 +171,54 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
         return (long)((uint32_t)live_chips[k] * (uint32_t)rows_per_chip + ((uint32_t)cr - k * (uint32_t)rows_per_chip));
     };
     // The bytes of block i+1 are fetched into registers while block i is in conv1 and parked in LDS once conv1 is
-    // done with s_in: the HBM latency of the int8 rows never sits between two barriers.
-    float pf[G::NPF], pfv = 0.0f;
+    // done with s_in: the HBM latency of the int8 rows never sits between two barriers.  A WAVE fetches whole rows (rows
+    // wave, wave + 8 of the block): the row pointer is wave-uniform (scalar registers, the live list is read with scalar
+    // loads), the lanes add lane + 64 v.  Per-thread element indices (row = i / 243 per lane) made the compiler hoist eight
+    // 64-bit row offsets per lane out of the loop, spill them, and wait on every reload -- which, the memory counter being
+    // in-order, also waited on the previous row byte: the eight loads of a block ran one after the other.
+    constexpr int RPW = (G::RB + 7) / 8, ROWB = 245;  // rows per wave; bytes of a row: 243 pixels, dir_x, dir_y
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int pf[RPW][4], pfo[RPW];
+    int pf_rv = 0;
+#pragma unroll
+    for (int h = 0; h < RPW; ++h) {
+        pfo[h] = 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) pf[h][v] = 0;
+    }
+    const int p3 = min(lane + 192, mlp_w ? ROWB - 1 : 242);  // the two direction bytes exist only with the vector branch
     auto fetch = [&](long b) {
         const long r0 = b * G::RB;
-        const int rvb = b < n_blocks ? (int)min((long)G::RB, rows - r0) : 0;
+        pf_rv = b < n_blocks ? (int)min((long)G::RB, rows - r0) : 0;
 #pragma unroll
-        for (int u = 0; u < G::NPF; ++u) {
-            const int i = tid + u * kBlockM, rr = i / 243, p = i - rr * 243;
-            pf[u] = (i < G::RB * 243 && rr < rvb) ? (float)obs[src_row(r0 + rr) * obs_stride + p] : 0.0f;  // rows past the end: finite zeros
-        }
-        if (mlp_w && tid < G::RB * G::VEC) {
-            const int rr = tid / G::VEC, k = tid - rr * G::VEC;
-            pfv = 0.0f;
-            if (rr < rvb) {
+        for (int h = 0; h < RPW; ++h) {
+            const int rr = wave_u + 8 * h;
+            if (rr < pf_rv) {  // wave-uniform
                 const long sr = src_row(r0 + rr);
-                if (k < 2) pfv = (float)obs[sr * obs_stride + 243 + k];
-                else if (onehot && k < nin) pfv = (float)onehot[sr * n_actions + (k - 2)];
+                const int8_t *row = obs + sr * obs_stride;
+                pf[h][0] = row[lane];
+                pf[h][1] = row[lane + 64];
+                pf[h][2] = row[lane + 128];
+                pf[h][3] = row[p3];
+                if (mlp_w && onehot && n_actions > 0) pfo[h] = onehot[sr * n_actions + min(lane, n_actions - 1)];
             }
         }
     };
     auto park = [&]() {
 #pragma unroll
-        for (int u = 0; u < G::NPF; ++u) {
-            const int i = tid + u * kBlockM, rr = i / 243, p = i - rr * 243;
-            if (i < G::RB * 243) s_in[rr * G::IN_STRIDE + p] = pf[u];
+        for (int h = 0; h < RPW; ++h) {
+            const int rr = wave_u + 8 * h;
+            if (rr < G::RB) {
+                const bool on = rr < pf_rv;   // rows past the end: finite zeros
+                float *dst = s_in + rr * G::IN_STRIDE;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) dst[lane + 64 * v] = on ? (float)pf[h][v] : 0.0f;
+                const float last = on ? (float)pf[h][3] : 0.0f;
+                if (lane + 192 < 243) dst[lane + 192] = last;
+                else if (lane + 192 < ROWB) s_vec[rr * G::VEC + lane + 192 - 243] = last;
+                if (lane < 16) s_vec[rr * G::VEC + 2 + lane] = (on && onehot && lane < n_actions) ? (float)pfo[h] : 0.0f;
+            }
         }
-        if (mlp_w && tid < G::RB * G::VEC) s_vec[tid] = pfv;
     };
     // Two barriers per row block.  B2 (after conv1) frees s_in / s_vec: the NEXT block's rows, fetched into registers before conv1,
     // are parked right behind it, while conv2 runs.  B3 (after conv2) publishes the staged rows and the parked inputs.  There
@@ -206,8 +234,8 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
         float mv = 0.0f;  // vector branch: relu(mlp1([dir_x, dir_y, last-action one-hot])) (base_net.py:66); s_vec is re-parked behind B2
         const int mr = tid / 10, mc = tid - mr * 10;
         if (mlp_w && tid < G::RB * 10) {
-            mv = mlp_b[mc];
-            for (int k = 0; k < nin; ++k) mv = fmaf(s_vec[mr * G::VEC + k], mlp_w[mc * nin + k], mv);
+            mv = s_mlp[10 * G::VEC + mc];
+            for (int k = 0; k < nin; ++k) mv = fmaf(s_vec[mr * G::VEC + k], s_mlp[mc * nin + k], mv);
         }
         fetch(blk + gridDim.x);
         // ---- conv1
@@ -217,11 +245,17 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
             // (quarter qt: p = 16 qt + i), position 48 of all RB rows is one more tile.  Wave `sub` takes rows
             // sub, sub + 4, ...: three accumulator chains per row; the gathers of the next row are in flight while
             // the MFMAs of the current one issue.  Addresses are per-lane constants + compile-time offsets.
+            // The 21 gather addresses goff[qt] + off1[s] are formed HERE, per row block (the empty asm hides goff from the
+            // loop-invariant code motion): hoisted out of the block loop they stayed live through conv2 and the stream-out
+            // as well, and the kernel spilled.
+            int gq[3];
+#pragma unroll
+            for (int qt = 0; qt < 3; ++qt) { gq[qt] = goff[qt] + sub * G::IN_STRIDE; asm volatile("" : "+v"(gq[qt])); }
             float cv[2][3][7];
 #pragma unroll
             for (int qt = 0; qt < 3; ++qt)
 #pragma unroll
-                for (int s = 0; s < 7; ++s) cv[0][qt][s] = s_in[sub * G::IN_STRIDE + goff[qt] + off1[s]];
+                for (int s = 0; s < 7; ++s) cv[0][qt][s] = s_in[gq[qt] + off1[s]];
 #pragma unroll
             for (int i = 0; i < G::RB / 4; ++i) {
                 if (i + 1 < G::RB / 4) {
@@ -229,7 +263,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
                     for (int qt = 0; qt < 3; ++qt)
 #pragma unroll
                         for (int s = 0; s < 7; ++s)
-                            cv[(i + 1) & 1][qt][s] = s_in[(sub + 4 * (i + 1)) * G::IN_STRIDE + goff[qt] + off1[s]];
+                            cv[(i + 1) & 1][qt][s] = s_in[4 * (i + 1) * G::IN_STRIDE + gq[qt] + off1[s]];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc[3];
@@ -267,6 +301,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
 #ifndef CRNN_PROBE_SKIP_CONV2
         {
             int t = sub;
+#pragma unroll 1
             for (; t + 4 < G::T2; t += 8) conv2_tiles<OD, RBV, 2>(s_a1, s_out, bw2, bias2, t, t + 4, j, kq, ch, chv);
             if (t < G::T2) conv2_tiles<OD, RBV, 1>(s_a1, s_out, bw2, bias2, t, t, j, kq, ch, chv);
         }

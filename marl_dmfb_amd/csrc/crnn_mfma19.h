@@ -35,10 +35,12 @@ template <int OD> struct Geo {
     static constexpr int M2 = RB * 49, M3 = RB * 25;
     static constexpr int T2 = (M2 + 15) / 16, T3 = (M3 + 15) / 16;
     static constexpr int VEC = 18;                       // dir_x, dir_y, one-hot (<= 16) per row
-    static constexpr int NPF = (RB * kPix + kBlockM - 1) / kBlockM;  // pixel bytes prefetched per thread
+    static constexpr int RPW = (RB + 7) / 8;             // rows a wave fetches per block
+    static constexpr int ROWB = kPix + 2, NLD = (ROWB + 63) / 64;     // bytes of a row, byte loads per lane and row
+    static constexpr int MLP = 10 * VEC + 10;            // the vector branch's weights [10][nin] and biases
     static_assert(RB % 4 == 0 && RB <= 16, "stage-1 tiling: rows split over 4 waves per channel half, one position-80 tile");
     static_assert(OUT_STRIDE <= ROW_A1, "the staged output rows overlay the stage-1 activations");
-    static constexpr size_t LDS_FLOATS = (size_t)RB * IMG / 4 + (size_t)RB * ROW_A1 + (size_t)RB * ROW_A2 + (size_t)RB * VEC;
+    static constexpr size_t LDS_FLOATS = (size_t)RB * IMG / 4 + (size_t)RB * ROW_A1 + (size_t)RB * ROW_A2 + (size_t)RB * VEC + MLP;
 };
 
 // conv3 (3x3, stride 1) for NT (1 or 2) tiles of 16 output positions, input planes IW x IW (channel stride CS_IN, row
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv19_mfma(const int8_t *__restric
     float *s_a1 = lds + G::RB * G::IMG / 4;             // [RB][OD][85] stage-1 activations (9x9)
     float *s_a2 = s_a1 + G::RB * G::ROW_A1;             // [RB][OD][53] stage-2 activations (7x7)
     float *s_vec = s_a2 + G::RB * G::ROW_A2;            // [RB][18] inputs of the vector branch
+    float *s_mlp = s_vec + G::RB * G::VEC;              // [10][nin] weights, then [10] biases of the vector branch
     float *s_out = s_a1;                                // [RB][OUT_STRIDE], overlays s_a1 (dead after stage 2)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // wave w runs on SIMD w & 3: SIMDs 0,1 hold channel half 0, SIMDs 2,3 half 1; the two waves of a SIMD take tiles
@@ -169,34 +172,60 @@ __global__ __launch_bounds__(kBlockM) void k_conv19_mfma(const int8_t *__restric
 
     const long n_blocks = (rows + G::RB - 1) / G::RB;
     const int nin = 2 + n_actions;
-    // The pixel bytes of the next block are loaded and parked in LDS right after stage 1 is done with s_img: the load
-    // latency is paid once per block (~2 of ~50 us) while the SIMD's other wave runs stage 2; holding them in registers
-    // across stage 1 instead (as crnn_mfma.h does for its 243-byte rows) would spill here.
-    auto stage_in = [&](long b) {
-        const long r0 = b * G::RB;
-        const int rvb = b < n_blocks ? (int)min((long)G::RB, rows - r0) : 0;
-        int pf[G::NPF];
+    // The vector branch's parameters live in LDS (crnn_mfma.h: a global load at the head of a row block also waits for the
+    // previous block's output stores).
+    if (mlp_w) {
+        for (int i = tid; i < 10 * nin; i += kBlockM) s_mlp[i] = mlp_w[i];
+        if (tid < 10) s_mlp[10 * G::VEC + tid] = mlp_b[tid];
+    }
+    // The bytes of the next block are fetched right after stage 1 is done with s_img and parked behind stage 2: their latency
+    // is covered by stage 2.  A WAVE fetches whole rows with a wave-uniform row pointer and lane + 64 v offsets (crnn_mfma.h:
+    // per-thread element indices made the compiler spill hoisted row offsets and wait on every reload, which serialised the
+    // 17 byte loads of a block).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int pf[G::RPW][G::NLD], pfo[G::RPW];
+    int pf_rv = 0;
 #pragma unroll
-        for (int u = 0; u < G::NPF; ++u) {
-            const int i = tid + u * kBlockM, rr = i / kPix, p = i - rr * kPix;
-            pf[u] = (i < G::RB * kPix && rr < rvb) ? (int)obs[(r0 + rr) * obs_stride + p] : 0;  // rows past the end: zeros
-        }
-        float pfv = 0.0f;
-        if (mlp_w && tid < G::RB * G::VEC) {
-            const int rr = tid / G::VEC, k = tid - rr * G::VEC;
-            if (rr < rvb) {
-                if (k < 2) pfv = (float)obs[(r0 + rr) * obs_stride + kPix + k];
-                else if (onehot && k < nin) pfv = (float)onehot[(r0 + rr) * n_actions + (k - 2)];
+    for (int h = 0; h < G::RPW; ++h) {
+        pfo[h] = 0;
+#pragma unroll
+        for (int v = 0; v < G::NLD; ++v) pf[h][v] = 0;
+    }
+    const int p_last = min(lane + 64 * (G::NLD - 1), mlp_w ? G::ROWB - 1 : kPix - 1);  // the direction bytes exist only with the vector branch
+    auto fetch = [&](long b) {
+        const long r0 = b * G::RB;
+        pf_rv = b < n_blocks ? (int)min((long)G::RB, rows - r0) : 0;
+#pragma unroll
+        for (int h = 0; h < G::RPW; ++h) {
+            const int rr = wave_u + 8 * h;
+            if (rr < pf_rv) {  // wave-uniform
+                const int8_t *row = obs + (r0 + rr) * obs_stride;
+#pragma unroll
+                for (int v = 0; v + 1 < G::NLD; ++v) pf[h][v] = row[lane + 64 * v];
+                pf[h][G::NLD - 1] = row[p_last];
+                if (mlp_w && onehot && n_actions > 0) pfo[h] = onehot[(r0 + rr) * n_actions + min(lane, n_actions - 1)];
             }
         }
-#pragma unroll
-        for (int u = 0; u < G::NPF; ++u) {
-            const int i = tid + u * kBlockM, rr = i / kPix, p = i - rr * kPix;
-            if (i < G::RB * kPix) s_img[rr * G::IMG + p] = (int8_t)pf[u];
-        }
-        if (mlp_w && tid < G::RB * G::VEC) s_vec[tid] = pfv;
     };
-    stage_in(blockIdx.x);
+    auto park = [&]() {
+#pragma unroll
+        for (int h = 0; h < G::RPW; ++h) {
+            const int rr = wave_u + 8 * h;
+            if (rr < G::RB) {
+                const bool on = rr < pf_rv;   // rows past the end: zeros
+                int8_t *dst = s_img + rr * G::IMG;
+#pragma unroll
+                for (int v = 0; v + 1 < G::NLD; ++v) dst[lane + 64 * v] = on ? (int8_t)pf[h][v] : (int8_t)0;
+                const int pl = lane + 64 * (G::NLD - 1);
+                const int last = on ? pf[h][G::NLD - 1] : 0;
+                if (pl < kPix) dst[pl] = (int8_t)last;
+                else if (pl < G::ROWB) s_vec[rr * G::VEC + pl - kPix] = (float)last;
+                if (lane < 16) s_vec[rr * G::VEC + 2 + lane] = (on && onehot && lane < n_actions) ? (float)pfo[h] : 0.0f;
+            }
+        }
+    };
+    fetch(blockIdx.x);
+    park();
     for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const long row0 = blk * G::RB;
         const int rv = (int)min((long)G::RB, rows - row0);
@@ -204,18 +233,23 @@ __global__ __launch_bounds__(kBlockM) void k_conv19_mfma(const int8_t *__restric
         float mv = 0.0f;  // vector branch: relu(mlp1([dir_x, dir_y, last-action one-hot])) (base_net.py:66)
         const int mr = tid / 10, mc = tid - mr * 10;
         if (mlp_w && tid < G::RB * 10) {
-            mv = mlp_b[mc];
-            for (int k = 0; k < nin; ++k) mv = fmaf(s_vec[mr * G::VEC + k], mlp_w[mc * nin + k], mv);
+            mv = s_mlp[10 * G::VEC + mc];
+            for (int k = 0; k < nin; ++k) mv = fmaf(s_vec[mr * G::VEC + k], s_mlp[mc * nin + k], mv);
         }
         // ---- stage 1: stride-2 conv of the image.  A row's positions 0..79 are five tiles (p = 16 qt + i), position
         // 80 of all RB rows is one more tile.  Wave `sub` takes rows sub, sub + 4, ...
         {
+            // the 35 gather addresses goff[qt] + off1[s] are formed per row block (the empty asm hides goff from the
+            // loop-invariant code motion; hoisted, they stayed live through stages 2 and 3 and the kernel spilled)
+            int gq[5];
+#pragma unroll
+            for (int qt = 0; qt < 5; ++qt) { gq[qt] = goff[qt]; asm volatile("" : "+v"(gq[qt])); }
 #pragma unroll 1
             for (int i = 0; i < G::RB / 4; ++i) {
                 const int8_t *img = s_img + (sub + 4 * i) * G::IMG;
                 float *dst = s_a1 + (sub + 4 * i) * G::ROW_A1 + ch * G::CS1 + kq * 4;
-                stage1_tiles<0, 3>(img, dst, goff, off1, bw1, bias1, chv);
-                stage1_tiles<3, 2>(img, dst, goff, off1, bw1, bias1, chv);
+                stage1_tiles<0, 3>(img, dst, gq, off1, bw1, bias1, chv);
+                stage1_tiles<3, 2>(img, dst, gq, off1, bw1, bias1, chv);
             }
             if (sub == 0) {  // position 80 (x = y = 8) of every row: lane i gathers row i
                 const int rr = j < G::RB ? j : G::RB - 1;
@@ -231,18 +265,21 @@ __global__ __launch_bounds__(kBlockM) void k_conv19_mfma(const int8_t *__restric
             }
         }
         __syncthreads();
-        stage_in(blk + gridDim.x);  // s_img / s_vec were last read before this barrier
+        fetch(blk + gridDim.x);  // s_img / s_vec were last read before this barrier
         // ---- stage 2: conv3 on the 9x9 planes
         {
             int t = sub;
+#pragma unroll 1
             for (; t + 4 < G::T2; t += 8)
                 conv3_tiles<OD, 2, 9, 7, G::CS1, G::ROW_A1, G::M2>(s_a1, s_a2, G::ROW_A2, G::CS2, bw3, bias3, t, t + 4, j, kq, ch, chv);
             if (t < G::T2) conv3_tiles<OD, 1, 9, 7, G::CS1, G::ROW_A1, G::M2>(s_a1, s_a2, G::ROW_A2, G::CS2, bw3, bias3, t, t, j, kq, ch, chv);
         }
+        park();
         __syncthreads();
         // ---- stage 3: the same conv3 on the 7x7 planes, into the staged output rows
         {
             int t = sub;
+#pragma unroll 1
             for (; t + 4 < G::T3; t += 8)
                 conv3_tiles<OD, 2, 7, 5, G::CS2, G::ROW_A2, G::M3>(s_a2, s_out, G::OUT_STRIDE, 25, bw3, bias3, t, t + 4, j, kq, ch, chv);
             if (t < G::T3) conv3_tiles<OD, 1, 7, 5, G::CS2, G::ROW_A2, G::M3>(s_a2, s_out, G::OUT_STRIDE, 25, bw3, bias3, t, t, j, kq, ch, chv);
