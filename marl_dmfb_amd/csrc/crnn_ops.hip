@@ -44,7 +44,7 @@ template <int OD> struct GeoB {
     static constexpr int FIXED_FLOATS = OD * OD * 9;
     static constexpr int RBB = ((kLdsBudget / 4 - FIXED_FLOATS) / ROW_FLOATS) < (kBlock / (2 * OD)) ? ((kLdsBudget / 4 - FIXED_FLOATS) / ROW_FLOATS)
                                                                                                    : (kBlock / (2 * OD));
-    static constexpr size_t LDS_FLOATS = (size_t)FIXED_FLOATS + (size_t)RBB * ROW_FLOATS;
+    static constexpr size_t LDS_FLOATS = (size_t)FIXED_FLOATS + (size_t)RBB * ROW_FLOATS + OD * 28;  // + conv1 weights and biases
     static constexpr int PAIRS = OD * OD;
     // (c2, c1) pairs beyond the first kBlock: either exactly one more per thread (od 32) or a remainder that is
     // spread over all threads by giving each (pair, row slice) to a different thread (od 24: 64 pairs x 8 slices)
@@ -72,7 +72,10 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     float *s_dz2 = s_a1 + G::RBB * OD * kA1Stride;      // [RBB][OD][28]
     float *s_in = s_dz2 + G::RBB * G::DZ_ROW;            // [RBB][244]
     float *s_dz1 = s_in + G::RBB * 244;                 // [RBB][OD][52]
+    float *s_w1 = s_dz1 + G::RBB * OD * kA1Stride;      // [OD][27] conv1 weights, then [OD] biases
     const int tid = threadIdx.x;
+    for (int i = tid; i < OD * 27; i += kBlock) s_w1[i] = w1[i];
+    if (tid < OD) s_w1[OD * 27 + tid] = b1[tid];
     for (int i = tid; i < OD * OD * 9; i += kBlock) {   // global (c2, c1, tap) -> LDS (c2, tap, c1)
         const int c2 = i / (OD * 9), rem = i - c2 * OD * 9, c1 = rem / 9, tap = rem - c1 * 9;
         s_w2[(c2 * 9 + tap) * OD + c1] = w2[i];
@@ -103,27 +106,32 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     const int c_nh = (wave >> 1) & 1, c_sub = (wave & 1) + 2 * (wave >> 2), c_ch = c_nh * 16 + j16;
     const bool c_chv = c_ch < OD;
     constexpr int NPD = (G::RBB * OD * 25 + kBlock - 1) / kBlock, NPI = (G::RBB * 243 + kBlock - 1) / kBlock;
-    float pfd[NPD], pfi[NPI];
+    // The prefetch is branch-free: clamped (always valid) addresses, RAW values in the registers; dz2 = g * (a2 > 0) and the
+    // int -> float conversion happen when the block is parked.  With the select at the load, every slot waited for its own
+    // pair of loads before the next slot's were issued: 17 global-memory latencies in a row per block.
+    float pfa[NPD], pfg[NPD];
+    int pfi[NPI];
+#pragma unroll
+    for (int u = 0; u < NPD; ++u) { pfa[u] = 0.0f; pfg[u] = 0.0f; }
+#pragma unroll
+    for (int u = 0; u < NPI; ++u) pfi[u] = 0;
     auto fetch = [&](long b) {
         const long r0 = b * G::RBB;
         const int rvb = b < blk1 ? (int)min((long)G::RBB, rows - r0) : 0;
+        if (rvb <= 0) return;  // uniform: nothing follows this block
         int t_ = tid;
         asm volatile("" : "+v"(t_));  // opaque: keeps the index arithmetic below out of the loop-invariant registers
 #pragma unroll
         for (int u = 0; u < NPD; ++u) {
-            const int i = t_ + u * kBlock, rr = i / (OD * 25), rem = i - rr * OD * 25;
-            float v = 0.0f;
-            if (i < G::RBB * OD * 25 && rr < rvb) {
-                const float act = a2[(r0 + rr) * a2_stride + rem];
-                const float gv = g[(r0 + rr) * g_stride + rem];
-                v = act > 0.0f ? gv : 0.0f;
-            }
-            pfd[u] = v;
+            const int i = min(t_ + u * kBlock, G::RBB * OD * 25 - 1), rr = i / (OD * 25), rem = i - rr * OD * 25;
+            const long row = r0 + min(rr, rvb - 1);
+            pfa[u] = a2[row * a2_stride + rem];
+            pfg[u] = g[row * g_stride + rem];
         }
 #pragma unroll
         for (int u = 0; u < NPI; ++u) {
-            const int i = t_ + u * kBlock, rr = i / 243, pp = i - rr * 243;
-            pfi[u] = (i < G::RBB * 243 && rr < rvb) ? (float)obs[(r0 + rr) * obs_stride + pp] : 0.0f;
+            const int i = min(t_ + u * kBlock, G::RBB * 243 - 1), rr = i / 243, pp = i - rr * 243;
+            pfi[u] = obs[(r0 + min(rr, rvb - 1)) * obs_stride + pp];
         }
     };
     fetch(blk0);
@@ -137,15 +145,15 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
 #pragma unroll
         for (int u = 0; u < NPD; ++u) {
             const int i = t_ + u * kBlock, rc = i / 25, k = i - rc * 25;
-            if (i < G::RBB * OD * 25) s_dz2[(rc / OD) * G::DZ_ROW + (rc % OD) * G::DZ2 + k] = pfd[u];
+            if (i < G::RBB * OD * 25) s_dz2[(rc / OD) * G::DZ_ROW + (rc % OD) * G::DZ2 + k] = (rc / OD < rv && pfa[u] > 0.0f) ? pfg[u] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < NPI; ++u) {
             const int i = t_ + u * kBlock, rr = i / 243, pp = i - rr * 243;
-            if (i < G::RBB * 243) s_in[rr * 244 + pp] = pfi[u];
+            if (i < G::RBB * 243) s_in[rr * 244 + pp] = rr < rv ? (float)pfi[u] : 0.0f;  // rows past the end: finite zeros
         }
         __syncthreads();
-        // the conv1 B operands are re-read from L2 every block: nothing of this phase stays in registers
+        // the conv1 B operands are re-read from LDS every block: nothing of this phase stays in registers
         // while the gradient phases run at the register limit
         int off1[7], goff[3];
         float bw1[7];
@@ -155,9 +163,10 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         for (int s = 0; s < 7; ++s) {
             const int k = 4 * s + kq_, c0 = k / 9, tap = k - c0 * 9;
             off1[s] = k < 27 ? c0 * 81 + (tap / 3) * 9 + tap % 3 : 0;
-            bw1[s] = (c_chv && k < 27) ? w1[c_ch * 27 + k] : 0.0f;
+            const float w = s_w1[(c_chv ? c_ch : 0) * 27 + (k < 27 ? k : 0)];
+            bw1[s] = (c_chv && k < 27) ? w : 0.0f;
         }
-        const float c_bias = c_chv ? b1[c_ch] : 0.0f;
+        const float c_bias = c_chv ? s_w1[OD * 27 + c_ch] : 0.0f;
 #pragma unroll
         for (int qt = 0; qt < 3; ++qt) { const int p = qt * 16 + j_; goff[qt] = (p / 7) * 9 + p % 7; }
         for (int rr = c_sub; rr < G::RBB; rr += 4) {
@@ -194,7 +203,8 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         }
         __syncthreads();
         // ---- P1: dW2 (and db2)
-        auto pair_rows = [&](int c2, int c1, int r_begin, int r_step, float (&acc)[9], float *sum_dz) {
+        auto pair_rows = [&](int c2, int c1, int r_begin, int r_step, float (&acc)[9], bool sum_dz) -> float {
+            float sum = 0.0f;
             for (int rr = r_begin; rr < rv; rr += r_step) {
                 float dz[G::DZ2], a[kA1Stride];
                 const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + rr * G::DZ_ROW + c2 * G::DZ2, 16);
@@ -216,13 +226,14 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
                     float t = 0.0f;
 #pragma unroll
                     for (int k = 0; k < 25; ++k) t += dz[k];
-                    *sum_dz += t;
+                    sum += t;
                 }
             }
+            return sum;
         };
 #ifndef CRNN_PROBE_SKIP_P1
-        if (pa_on) pair_rows(pa_c2, pa_c1, 0, 1, accA, pa_c1 == 0 ? &accB2 : nullptr);
-        if (px_on) pair_rows(px_c2, px_c1, px_slice, (G::EXTRA == kBlock) ? 1 : G::XSLICES, accX, px_c1 == 0 ? &accB2x : nullptr);
+        if (pa_on) accB2 += pair_rows(pa_c2, pa_c1, 0, 1, accA, pa_c1 == 0);
+        if (px_on) accB2x += pair_rows(px_c2, px_c1, px_slice, (G::EXTRA == kBlock) ? 1 : G::XSLICES, accX, px_c1 == 0);
 #endif
         // ---- P2: da1 partial sums over half of the c2 range; half 1 parks its partial in s_dz1
         const int half = tid / (G::RBB * OD), rem2 = tid - half * G::RBB * OD;
@@ -276,27 +287,26 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         if (p3_on) {
 #endif
             for (int rr = s3; rr < rv; rr += G::RS3) {
-                float dz[kA1Stride];
-                const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz1 + (rr * OD + c1_3) * kA1Stride, 16);
-#pragma unroll
-                for (int j = 0; j < kA1Stride / 4; ++j) { const float4 t = pd[j]; dz[4 * j] = t.x; dz[4 * j + 1] = t.y; dz[4 * j + 2] = t.z; dz[4 * j + 3] = t.w; }
+                // one 7-wide line of dz1 at a time: the whole 7x7 plane in registers (52) next to the prefetched block (29)
+                // went over the register file and the tail of the prefetch was spilled load by load
+                const float *pd = s_dz1 + (rr * OD + c1_3) * kA1Stride;
                 const float *in = s_in + rr * 244 + c0_3 * 81 + kx_3 * 9;
+                float t = 0.0f;
 #pragma unroll
                 for (int x = 0; x < 7; ++x) {
-                    float v[9];
+                    float dz[7], v[9];
+#pragma unroll
+                    for (int y = 0; y < 7; ++y) dz[y] = pd[x * 7 + y];
 #pragma unroll
                     for (int y = 0; y < 9; ++y) v[y] = in[x * 9 + y];
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                        for (int y = 0; y < 7; ++y) accW1[ky] = fmaf(dz[x * 7 + y], v[y + ky], accW1[ky]);
-                }
-                if (c0_3 == 0 && kx_3 == 0) {  // db1[c1] over this thread's row slice: dz1 is in registers
-                    float t = 0.0f;
+                        for (int y = 0; y < 7; ++y) accW1[ky] = fmaf(dz[y], v[y + ky], accW1[ky]);
 #pragma unroll
-                    for (int k = 0; k < 49; ++k) t += dz[k];
-                    accB1 += t;
+                    for (int y = 0; y < 7; ++y) t += dz[y];
                 }
+                if (c0_3 == 0 && kx_3 == 0) accB1 += t;  // db1[c1] over this thread's row slice
             }
         }
     }
