@@ -44,6 +44,7 @@ template <int OD> struct GeoB19 {
     static constexpr int W_FLOATS = OD * WS;
     static constexpr int PFR = (OD * 25 + kBlockB - 1) / kBlockB;       // prefetched (a3, g) pairs per thread and row
     static constexpr int PFI = (kPix + kBlockB - 1) / kBlockB;         // prefetched image bytes per thread and row
+    static_assert(PFI <= 4, "packed into one register");
     static constexpr int N_W3 = OD * OD * 9, N_W1 = OD * 27;
     // partial vector of a workgroup: dW3 | dW1 | bias sums per thread: [kBlockB] dz3+dz2, [kBlockB] dz1
     static constexpr int PART = N_W3 + N_W1 + 2 * kBlockB;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
     // ---- the row block's inputs travel one iteration ahead in registers: dz3's two sources (a3, g) of the 5x5 interior and the
     // image bytes.  Slot s of a thread is element tid + s * kBlockB of [RBB][OD][25] resp. [RBB][361].
     float pf_a[G::RBB][G::PFR], pf_g[G::RBB][G::PFR];
-    int8_t pf_i[G::RBB][G::PFI];
+    uint32_t pf_i[G::RBB];                    // PFI (3) image bytes of a row packed into one register
     int pf_dst[G::PFR];                       // where feature tid + h * kBlockB of a row lands in its padded planes
 #pragma unroll
     for (int h = 0; h < G::PFR; ++h) {
@@ -196,9 +197,13 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
                 pf_a[rr][h] = in ? pa[h * kBlockB] : 0.0f;
                 pf_g[rr][h] = in ? pg[h * kBlockB] : 0.0f;
             }
+            uint32_t pk = 0;
 #pragma unroll
-            for (int h = 0; h < G::PFI; ++h)
-                pf_i[rr][h] = (on && tid + h * kBlockB < kPix) ? obs[(row0 + rr) * obs_stride + tid + h * kBlockB] : (int8_t)0;
+            for (int h = 0; h < G::PFI; ++h) {
+                const uint32_t b = (on && tid + h * kBlockB < kPix) ? (uint8_t)obs[(row0 + rr) * obs_stride + tid + h * kBlockB] : 0u;
+                pk |= b << (8 * h);
+            }
+            pf_i[rr] = pk;
         }
     };
 
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
         for (int rr = 0; rr < G::RBB; ++rr)
 #pragma unroll
             for (int h = 0; h < G::PFI; ++h)
-                if (tid + h * kBlockB < kPix) s_img[rr * G::IMG + tid + h * kBlockB] = pf_i[rr][h];
+                if (tid + h * kBlockB < kPix) s_img[rr * G::IMG + tid + h * kBlockB] = (int8_t)(pf_i[rr] >> (8 * h));
 #pragma unroll 1
         for (int i = tid; i < G::RBB * OD * 56; i += kBlockB) {   // 56 border cells of a 9x9 plane around its 5x5 interior
             const int pl = i / 56, b = i - pl * 56;

@@ -120,40 +120,6 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
     const int ch = nh * 16 + j;                     // the output channel this lane's B column / D column belongs to
     const bool chv = ch < OD;
 
-    // ---- B operands (weights of channel ch) and the lane's conv1 gather offsets.  The weights go through LDS: read straight
-    // from global memory every lane of a wave hits a different cache line (channel stride 9 od floats), 61 such loads x 8 waves
-    // through the CU's one address unit cost ~15 us per launch; staged with coalesced loads the prologue is ~1 us.
-    for (int i = tid; i < OD * OD * 9; i += kBlockM) s_a1[i] = w2[i];   // [c_out][c_in][tap], s_a1 is free until the first conv1
-    for (int i = tid; i < OD * 27; i += kBlockM) s_in[i] = w1[i];       // [c_out][27]
-    __syncthreads();
-    float bw1[7];
-    int off1[7];
-#pragma unroll
-    for (int s = 0; s < 7; ++s) {
-        const int k = 4 * s + kq;
-        const bool kv = k < 27;
-        bw1[s] = (chv && kv) ? s_in[ch * 27 + k] : 0.0f;
-        const int c0 = k / 9, tap = k - c0 * 9;
-        off1[s] = kv ? c0 * 81 + (tap / 3) * 9 + tap % 3 : 0;
-    }
-    int goff[3];
-#pragma unroll
-    for (int qt = 0; qt < 3; ++qt) { const int p = qt * 16 + j; goff[qt] = (p / 7) * 9 + p % 7; }
-    float bw2[G::NSTEP2];
-#pragma unroll
-    for (int cq = 0; cq < G::KQ; ++cq)
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) bw2[cq * 9 + tap] = chv ? s_a1[(ch * OD + 4 * cq + kq) * 9 + tap] : 0.0f;
-    __syncthreads();  // the staging areas are reused below (s_in by park(), s_a1 by conv1)
-    const float bias1 = chv ? b1[ch] : 0.0f, bias2 = chv ? b2[ch] : 0.0f;
-    const int n_feat = OD * 25 + (mlp_w ? 10 : 0);
-    const int n_out = out_cols > n_feat ? out_cols : n_feat;  // columns n_feat .. n_out-1 of a row are written as zeros
-    const bool wide_out = (out_stride % 2 == 0) && (((size_t)out) % 8 == 0) && (n_out % 2 == 0);
-    for (int i = tid; i < G::RB * (G::OUT_STRIDE - n_feat); i += kBlockM) {  // the zero tail of every staged row, once
-        const int rr = i / (G::OUT_STRIDE - n_feat), k = i - rr * (G::OUT_STRIDE - n_feat);
-        s_out[rr * G::OUT_STRIDE + n_feat + k] = 0.0f;
-    }
-
     if (live_chips) rows = min(rows, (long)n_live[0] * rows_per_chip);
     const long n_blocks = (rows + G::RB - 1) / G::RB;
     const int nin = 2 + n_actions;
@@ -220,12 +186,47 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
             }
         }
     };
+    fetch(blockIdx.x);  // in flight while the weights are staged; parked below
+
+    // ---- B operands (weights of channel ch) and the lane's conv1 gather offsets.  The weights go through LDS: read straight
+    // from global memory every lane of a wave hits a different cache line (channel stride 9 od floats), 61 such loads x 8 waves
+    // through the CU's one address unit cost ~15 us per launch; staged with coalesced loads the prologue is ~1 us.
+    for (int i = tid; i < OD * OD * 9; i += kBlockM) s_a1[i] = w2[i];   // [c_out][c_in][tap], s_a1 is free until the first conv1
+    for (int i = tid; i < OD * 27; i += kBlockM) s_in[i] = w1[i];       // [c_out][27]
+    __syncthreads();
+    float bw1[7];
+    int off1[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int k = 4 * s + kq;
+        const bool kv = k < 27;
+        bw1[s] = (chv && kv) ? s_in[ch * 27 + k] : 0.0f;
+        const int c0 = k / 9, tap = k - c0 * 9;
+        off1[s] = kv ? c0 * 81 + (tap / 3) * 9 + tap % 3 : 0;
+    }
+    int goff[3];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) { const int p = qt * 16 + j; goff[qt] = (p / 7) * 9 + p % 7; }
+    float bw2[G::NSTEP2];
+#pragma unroll
+    for (int cq = 0; cq < G::KQ; ++cq)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) bw2[cq * 9 + tap] = chv ? s_a1[(ch * OD + 4 * cq + kq) * 9 + tap] : 0.0f;
+    __syncthreads();  // the staging areas are reused below (s_in by park(), s_a1 by conv1)
+    const float bias1 = chv ? b1[ch] : 0.0f, bias2 = chv ? b2[ch] : 0.0f;
+    const int n_feat = OD * 25 + (mlp_w ? 10 : 0);
+    const int n_out = out_cols > n_feat ? out_cols : n_feat;  // columns n_feat .. n_out-1 of a row are written as zeros
+    const bool wide_out = (out_stride % 2 == 0) && (((size_t)out) % 8 == 0) && (n_out % 2 == 0);
+    for (int i = tid; i < G::RB * (G::OUT_STRIDE - n_feat); i += kBlockM) {  // the zero tail of every staged row, once
+        const int rr = i / (G::OUT_STRIDE - n_feat), k = i - rr * (G::OUT_STRIDE - n_feat);
+        s_out[rr * G::OUT_STRIDE + n_feat + k] = 0.0f;
+    }
+
     // Two barriers per row block.  B2 (after conv1) frees s_in / s_vec: the NEXT block's rows, fetched into registers before conv1,
     // are parked right behind it, while conv2 runs.  B3 (after conv2) publishes the staged rows and the parked inputs.  There
     // is NO barrier between a block's stream-out and the next block's conv1: conv1 reads s_in and writes s_a1, the stream-out
     // reads s_out -- a wave that has streamed its rows out starts on the next conv1 while slower waves still store, and s_out is
     // rewritten only behind the next B2, which every wave reaches after its stream-out.
-    fetch(blockIdx.x);
     park();
     __syncthreads();
     for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {

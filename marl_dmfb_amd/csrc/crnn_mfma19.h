@@ -140,36 +140,6 @@ __global__ __launch_bounds__(kBlockM) void k_conv19_mfma(const int8_t *__restric
     const int ch = nh * 16 + j;                         // the output channel this lane's B column / D column belongs to
     const bool chv = ch < OD;
 
-    // ---- B operands (weights of channel ch) and the lane's stage-1 gather offsets (bytes into the staged image).  The weights
-    // are staged through LDS with coalesced loads (crnn_mfma.h: read straight from global memory, every lane of a wave hits a
-    // different cache line and the scattered loads of 8 waves cost tens of microseconds per launch).
-    for (int i = tid; i < OD * OD * 9; i += kBlockM) s_a1[i] = w3[i];   // [c_out][c_in][tap]; s_a1 is free until the first stage 1
-    for (int i = tid; i < OD * 27; i += kBlockM) s_a2[i] = w1[i];       // [c_out][27]
-    __syncthreads();
-    float bw1[7];
-    int off1[7];
-#pragma unroll
-    for (int s = 0; s < 7; ++s) {
-        const int k = 4 * s + kq;
-        const bool kv = k < 27;
-        bw1[s] = (chv && kv) ? s_a2[ch * 27 + k] : 0.0f;
-        const int c0 = k / 9, tap = k - c0 * 9;
-        off1[s] = kv ? c0 * kFov * kFov + (tap / 3) * kFov + tap % 3 : 0;
-    }
-    int goff[5];
-#pragma unroll
-    for (int qt = 0; qt < 5; ++qt) { const int p = qt * 16 + j; goff[qt] = 2 * (p / 9) * kFov + 2 * (p % 9); }
-    float bw3[G::NSTEP];
-#pragma unroll
-    for (int cq = 0; cq < G::KQ; ++cq)
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) bw3[cq * 9 + tap] = chv ? s_a1[(ch * OD + 4 * cq + kq) * 9 + tap] : 0.0f;
-    __syncthreads();  // the staging areas are reused by the stages below
-    const float bias1 = chv ? b1[ch] : 0.0f, bias3 = chv ? b3[ch] : 0.0f;
-    const int n_feat = OD * 25 + (mlp_w ? 10 : 0);
-    const int n_out = out_cols > n_feat ? out_cols : n_feat;  // columns n_feat .. n_out-1 of a row are written as zeros
-    const bool wide_out = (out_stride % 2 == 0) && (((size_t)out) % 8 == 0) && (n_out % 2 == 0);
-
     const long n_blocks = (rows + G::RB - 1) / G::RB;
     const int nin = 2 + n_actions;
     // The vector branch's parameters live in LDS (crnn_mfma.h: a global load at the head of a row block also waits for the
@@ -224,7 +194,38 @@ __global__ __launch_bounds__(kBlockM) void k_conv19_mfma(const int8_t *__restric
             }
         }
     };
-    fetch(blockIdx.x);
+    fetch(blockIdx.x);  // in flight while the weights are staged; parked below
+
+    // ---- B operands (weights of channel ch) and the lane's stage-1 gather offsets (bytes into the staged image).  The weights
+    // are staged through LDS with coalesced loads (crnn_mfma.h: read straight from global memory, every lane of a wave hits a
+    // different cache line and the scattered loads of 8 waves cost tens of microseconds per launch).
+    for (int i = tid; i < OD * OD * 9; i += kBlockM) s_a1[i] = w3[i];   // [c_out][c_in][tap]; s_a1 is free until the first stage 1
+    for (int i = tid; i < OD * 27; i += kBlockM) s_a2[i] = w1[i];       // [c_out][27]
+    __syncthreads();
+    float bw1[7];
+    int off1[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int k = 4 * s + kq;
+        const bool kv = k < 27;
+        bw1[s] = (chv && kv) ? s_a2[ch * 27 + k] : 0.0f;
+        const int c0 = k / 9, tap = k - c0 * 9;
+        off1[s] = kv ? c0 * kFov * kFov + (tap / 3) * kFov + tap % 3 : 0;
+    }
+    int goff[5];
+#pragma unroll
+    for (int qt = 0; qt < 5; ++qt) { const int p = qt * 16 + j; goff[qt] = 2 * (p / 9) * kFov + 2 * (p % 9); }
+    float bw3[G::NSTEP];
+#pragma unroll
+    for (int cq = 0; cq < G::KQ; ++cq)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) bw3[cq * 9 + tap] = chv ? s_a1[(ch * OD + 4 * cq + kq) * 9 + tap] : 0.0f;
+    __syncthreads();  // the staging areas are reused by the stages below
+    const float bias1 = chv ? b1[ch] : 0.0f, bias3 = chv ? b3[ch] : 0.0f;
+    const int n_feat = OD * 25 + (mlp_w ? 10 : 0);
+    const int n_out = out_cols > n_feat ? out_cols : n_feat;  // columns n_feat .. n_out-1 of a row are written as zeros
+    const bool wide_out = (out_stride % 2 == 0) && (((size_t)out) % 8 == 0) && (n_out % 2 == 0);
+
     park();
     for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const long row0 = blk * G::RB;
