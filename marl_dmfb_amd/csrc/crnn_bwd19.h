@@ -388,28 +388,40 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
     mine[G::N_W3 + G::N_W1 + kBlockB + tid] = b_on ? accb1 : 0.0f;
 }
 
-// grads = dW3 | db3 | dW1 | db1 from the n_part partial vectors, added in a fixed order
+// grads = dW3 | db3 | dW1 | db1 from the n_part partial vectors.  64 outputs per 1024-thread workgroup: thread (ty, tx) adds every
+// 16th partial vector of output tx (independent loads in flight), the 16 sub-sums meet in LDS in a fixed order (deterministic).
+constexpr int kRedY19 = 16;
 template <int OD>
-__global__ __launch_bounds__(256) void k_conv19_bwd_reduce(const float *__restrict__ part, int n_part, float *__restrict__ grads) {
+__global__ __launch_bounds__(64 * kRedY19) void k_conv19_bwd_reduce(const float *__restrict__ part, int n_part, float *__restrict__ grads) {
     using G = GeoB19<OD>;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= G::GRADS) return;
+    __shared__ float s_sum[kRedY19][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
     float s = 0.0f;
-    if (i < G::N_W3) {
-        for (int b = 0; b < n_part; ++b) s += part[(size_t)b * G::PART + i];
-    } else if (i < G::N_W3 + OD) {                               // db3[c]: the 16 position slices of every workgroup
-        const int c = i - G::N_W3;
-        for (int b = 0; b < n_part; ++b)
-            for (int sl = 0; sl < 16; ++sl) s += part[(size_t)b * G::PART + G::N_W3 + G::N_W1 + sl * OD + c];
-    } else if (i < G::N_W3 + OD + G::N_W1) {
-        const int k = i - G::N_W3 - OD;
-        for (int b = 0; b < n_part; ++b) s += part[(size_t)b * G::PART + G::N_W3 + k];
-    } else {
-        const int c = i - G::N_W3 - OD - G::N_W1;
-        for (int b = 0; b < n_part; ++b)
-            for (int sl = 0; sl < 16; ++sl) s += part[(size_t)b * G::PART + G::N_W3 + G::N_W1 + kBlockB + sl * OD + c];
+    if (i < G::GRADS) {
+        if (i < G::N_W3) {
+            for (int b = ty; b < n_part; b += kRedY19) s += part[(size_t)b * G::PART + i];
+        } else if (i < G::N_W3 + OD) {                               // db3[c]: the 16 position slices of every workgroup
+            const int c = i - G::N_W3;
+            for (int b = ty; b < n_part; b += kRedY19)
+                for (int sl = 0; sl < 16; ++sl) s += part[(size_t)b * G::PART + G::N_W3 + G::N_W1 + sl * OD + c];
+        } else if (i < G::N_W3 + OD + G::N_W1) {
+            const int k = i - G::N_W3 - OD;
+            for (int b = ty; b < n_part; b += kRedY19) s += part[(size_t)b * G::PART + G::N_W3 + k];
+        } else {
+            const int c = i - G::N_W3 - OD - G::N_W1;
+            for (int b = ty; b < n_part; b += kRedY19)
+                for (int sl = 0; sl < 16; ++sl) s += part[(size_t)b * G::PART + G::N_W3 + G::N_W1 + kBlockB + sl * OD + c];
+        }
     }
-    grads[i] = s;
+    s_sum[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < G::GRADS) {
+        float t = 0.0f;
+#pragma unroll
+        for (int y = 0; y < kRedY19; ++y) t += s_sum[y][tx];
+        grads[i] = t;
+    }
 }
 
 }  // namespace crnn_bwd19

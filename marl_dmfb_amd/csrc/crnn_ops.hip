@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         const int c2 = i / (OD * 9), rem = i - c2 * OD * 9, c1 = rem / 9, tap = rem - c1 * 9;
         s_w2[(c2 * 9 + tap) * OD + c1] = w2[i];
     }
-    float accA[9], accX[9], accW1[3], accB2 = 0.0f, accB2x = 0.0f, accB1 = 0.0f;  // persistent over all rows of the workgroup
+    float accA[9], accX[9], accW1[3], accB2 = 0.0f, accB1 = 0.0f;  // persistent over all rows of the workgroup
 #pragma unroll
     for (int k = 0; k < 9; ++k) { accA[k] = 0.0f; accX[k] = 0.0f; }
 #pragma unroll
@@ -95,6 +95,10 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     const int i3 = tid % G::ITEMS3, s3 = tid / G::ITEMS3;
     const bool p3_on = s3 < G::RS3;
     const int c1_3 = i3 / 9, c0_3 = (i3 - c1_3 * 9) / 3, kx_3 = i3 - c1_3 * 9 - c0_3 * 3;
+
+    // P2 role: (half of the c2 range, row r2, channel c1b); the half-0 threads also own the bias sums of (row r2, channel c1b)
+    const int half = tid / (G::RBB * OD), rem2 = tid - half * G::RBB * OD;
+    const int r2 = rem2 / OD, c1b = rem2 - r2 * OD;
 
     const long n_blocks = (rows + G::RBB - 1) / G::RBB;
     const long per = (n_blocks + gridDim.x - 1) / gridDim.x;
@@ -203,8 +207,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         }
         __syncthreads();
         // ---- P1: dW2 (and db2)
-        auto pair_rows = [&](int c2, int c1, int r_begin, int r_step, float (&acc)[9], bool sum_dz) -> float {
-            float sum = 0.0f;
+        auto pair_rows = [&](int c2, int c1, int r_begin, int r_step, float (&acc)[9]) {
             for (int rr = r_begin; rr < rv; rr += r_step) {
                 float dz[G::DZ2], a[kA1Stride];
                 const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + rr * G::DZ_ROW + c2 * G::DZ2, 16);
@@ -222,22 +225,22 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
 #pragma unroll
                             for (int y = 0; y < 5; ++y)
                                 acc[kx * 3 + ky] = fmaf(dz[x * 5 + y], a[(x + kx) * 7 + y + ky], acc[kx * 3 + ky]);
-                if (sum_dz) {  // db2[c2]: the thread of pair (c2, 0) already holds this row's dz2 in registers
-                    float t = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 25; ++k) t += dz[k];
-                    sum += t;
-                }
             }
-            return sum;
         };
+        // db2[c2] += sum of dz2[row][c2][.]: thread (row, c2) = the (r2, c1b) role of P2.  Inside pair_rows (the thread of pair
+        // (c2, 0) has the row's dz2 in registers) the 25 adds ran in every wave for one lane in 24.
+        if (tid < G::RBB * OD && r2 < rv) {
+            const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + r2 * G::DZ_ROW + c1b * G::DZ2, 16);
+            float t = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { const float4 v = pd[j]; t += (v.x + v.y) + (v.z + v.w); }
+            accB2 += t + pd[6].x;
+        }
 #ifndef CRNN_PROBE_SKIP_P1
-        if (pa_on) accB2 += pair_rows(pa_c2, pa_c1, 0, 1, accA, pa_c1 == 0);
-        if (px_on) accB2x += pair_rows(px_c2, px_c1, px_slice, (G::EXTRA == kBlock) ? 1 : G::XSLICES, accX, px_c1 == 0);
+        if (pa_on) pair_rows(pa_c2, pa_c1, 0, 1, accA);
+        if (px_on) pair_rows(px_c2, px_c1, px_slice, (G::EXTRA == kBlock) ? 1 : G::XSLICES, accX);
 #endif
         // ---- P2: da1 partial sums over half of the c2 range; half 1 parks its partial in s_dz1
-        const int half = tid / (G::RBB * OD), rem2 = tid - half * G::RBB * OD;
-        const int r2 = rem2 / OD, c1b = rem2 - r2 * OD;
 #ifndef CRNN_PROBE_SKIP_P2
         const bool p2 = half < 2 && r2 < rv;
 #else
@@ -266,17 +269,38 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
                                 da[(x + kx) * 7 + y + ky] = fmaf(dz[x * 5 + y], w[kx * 3 + ky], da[(x + kx) * 7 + y + ky]);
             }
             if (half == 1) {
-                float *dst = s_dz1 + (r2 * OD + c1b) * kA1Stride;
+                float4 *dst4 = (float4 *)__builtin_assume_aligned(s_dz1 + (r2 * OD + c1b) * kA1Stride, 16);
 #pragma unroll
-                for (int k = 0; k < 49; ++k) dst[k] = da[k];
+                for (int j = 0; j < 12; ++j) dst4[j] = make_float4(da[4 * j], da[4 * j + 1], da[4 * j + 2], da[4 * j + 3]);
+                dst4[12] = make_float4(da[48], 0.0f, 0.0f, 0.0f);
             }
         }
         __syncthreads();
         if (p2 && half == 0) {
-            float *dst = s_dz1 + (r2 * OD + c1b) * kA1Stride;
-            const float *act = s_a1 + (r2 * OD + c1b) * kA1Stride;
+            // dz1 = (da1 of both c2 halves) * (a1 > 0): all loads first (the ReLU mask as bits, then the other half's partial
+            // sums), selects, 16-byte stores.  Element by element the compiler kept load -> compare -> branch -> load -> store in
+            // order (the two LDS arrays may alias for all it knows): 98 LDS round trips one after the other per row block.
+            float4 *dst4 = (float4 *)__builtin_assume_aligned(s_dz1 + (r2 * OD + c1b) * kA1Stride, 16);
+            const float4 *act4 = (const float4 *)__builtin_assume_aligned(s_a1 + (r2 * OD + c1b) * kA1Stride, 16);
+            unsigned long long live = 0;
 #pragma unroll
-            for (int k = 0; k < 49; ++k) dst[k] = act[k] > 0.0f ? da[k] + dst[k] : 0.0f;
+            for (int j = 0; j < 13; ++j) {
+                const float4 a = act4[j];
+                live |= (unsigned long long)((a.x > 0.0f ? 1u : 0u) | (a.y > 0.0f ? 2u : 0u) | (a.z > 0.0f ? 4u : 0u) | (a.w > 0.0f ? 8u : 0u)) << (4 * j);
+            }
+            float4 other[13];
+#pragma unroll
+            for (int j = 0; j < 13; ++j) other[j] = dst4[j];
+#pragma unroll
+            for (int j = 0; j < 13; ++j) {
+                float4 o;
+                o.x = (live >> (4 * j)) & 1 ? da[4 * j] + other[j].x : 0.0f;
+                o.y = (4 * j + 1 < 49 && ((live >> (4 * j + 1)) & 1)) ? da[4 * j + 1 < 49 ? 4 * j + 1 : 0] + other[j].y : 0.0f;
+                o.z = (4 * j + 2 < 49 && ((live >> (4 * j + 2)) & 1)) ? da[4 * j + 2 < 49 ? 4 * j + 2 : 0] + other[j].z : 0.0f;
+                o.w = (4 * j + 3 < 49 && ((live >> (4 * j + 3)) & 1)) ? da[4 * j + 3 < 49 ? 4 * j + 3 : 0] + other[j].w : 0.0f;
+                dst4[j] = o;
+                accB1 += (o.x + o.y) + (o.z + o.w);  // db1[c1b] += sum of dz1[r2][c1b][.]
+            }
         }
         __syncthreads();
         fetch(blk + 1);  // lands while P3 runs; parked after the next barrier
@@ -291,7 +315,6 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
                 // went over the register file and the tail of the prefetch was spilled load by load
                 const float *pd = s_dz1 + (rr * OD + c1_3) * kA1Stride;
                 const float *in = s_in + rr * 244 + c0_3 * 81 + kx_3 * 9;
-                float t = 0.0f;
 #pragma unroll
                 for (int x = 0; x < 7; ++x) {
                     float dz[7], v[9];
@@ -303,35 +326,33 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                         for (int y = 0; y < 7; ++y) accW1[ky] = fmaf(dz[y], v[y + ky], accW1[ky]);
-#pragma unroll
-                    for (int y = 0; y < 7; ++y) t += dz[y];
                 }
-                if (c0_3 == 0 && kx_3 == 0) accB1 += t;  // db1[c1] over this thread's row slice
             }
         }
     }
-    // bias gradients: db1's RS3 (<= 2) row slices of a channel meet in LDS (two adds into zero: order-independent);
-    // db2[c2] sits with the thread of pair (c2, 0) -- first pass, or up to 8 row slices of the extra pass -- and is
-    // summed slot by slot in a fixed order
+    // bias gradients: thread (r2, c) of the first RBB * OD holds the sums of its row slot for db1[c] and db2[c]; the RBB slots of
+    // a channel meet in LDS and are added in a fixed order
     __syncthreads();
-    for (int i = tid; i < 64 + OD * 8; i += kBlock) s_dz2[i] = 0.0f;
-    __syncthreads();
-    if (p3_on && c0_3 == 0 && kx_3 == 0) atomicAdd(&s_dz2[c1_3], accB1);
-    if (pa_on && pa_c1 == 0) s_dz2[64 + pa_c2 * 8] = accB2;
-    if (px_on && px_c1 == 0) s_dz2[64 + px_c2 * 8 + (px_slice & 7)] = accB2x;
+    if (tid < G::RBB * OD) {
+        s_dz2[c1b * 16 + r2] = accB1;
+        s_dz2[OD * 16 + c1b * 16 + r2] = accB2;
+    }
     __syncthreads();
     float *pp = part + (size_t)blockIdx.x * G::PART;
 #pragma unroll
     for (int k = 0; k < 9; ++k) { pp[tid * 9 + k] = accA[k]; pp[kBlock * 9 + tid * 9 + k] = accX[k]; }
     if (tid < OD) {
         float t = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += s_dz2[64 + tid * 8 + k];
+        for (int k = 0; k < G::RBB; ++k) t += s_dz2[OD * 16 + tid * 16 + k];
         pp[kBlock * 18 + tid] = t;
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) pp[kBlock * 18 + OD + tid * 3 + k] = accW1[k];
-    if (tid < OD) pp[kBlock * 18 + OD + kBlock * 3 + tid] = s_dz2[tid];
+    if (tid < OD) {
+        float t = 0.0f;
+        for (int k = 0; k < G::RBB; ++k) t += s_dz2[tid * 16 + k];
+        pp[kBlock * 18 + OD + kBlock * 3 + tid] = t;
+    }
 }
 
 // Sum of the partial vectors -> the four gradient tensors (<= 256 x ~11k floats).  64 outputs per 1024-thread
@@ -494,7 +515,7 @@ int launch_bwd19(const int8_t *obs, long obs_stride, long rows, const float *a3,
     (void)hipGetLastError();
     hipLaunchKernelGGL((crnn_bwd19::k_conv19_bwd<OD>), dim3(grid), dim3(crnn_bwd19::kBlockB), lds, s, obs, obs_stride, rows, a3, a3_stride, g,
                        g_stride, w1, b1, w3, b3, part);
-    hipLaunchKernelGGL((crnn_bwd19::k_conv19_bwd_reduce<OD>), dim3((G::GRADS + 255) / 256), dim3(256), 0, s, part, grid, grads);
+    hipLaunchKernelGGL((crnn_bwd19::k_conv19_bwd_reduce<OD>), dim3((G::GRADS + 63) / 64), dim3(64 * crnn_bwd19::kRedY19), 0, s, part, grid, grads);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
     return CRNN_OK;
