@@ -22,6 +22,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlockM = 512;
 
+// tools/probe/conv_probe.hip -DCRNN_PROBE_TS: lane 0 of every wave stamps the shader-cycle counter at the phase boundaries of
+// its SECOND row block into g_crnn_ts[workgroup][wave][stamp]; compiled out of the product.
+#ifdef CRNN_PROBE_TS
+__device__ unsigned long long *g_crnn_ts;
+#define CRNN_TS(k) do { if (lane == 0 && ts_it == 1 && g_crnn_ts) g_crnn_ts[((size_t)blockIdx.x * 8 + wave) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CRNN_TS(k) do { } while (0)
+#endif
+
 // RBV: rows per workgroup iteration.  0 = the largest block one workgroup per CU can hold (16 rows at od 24, 12 at od 32:
 // 139 / 134 KB of LDS).  Two workgroups per CU (8 rows each) were built twice -- eight waves at 128 registers, and four waves
 // owning both channel halves -- and both measured SLOWER (register spills; tools/probe/conv9_mfma_w4.patch).
@@ -65,6 +74,11 @@ __device__ __forceinline__ void conv2_tiles(const float *s_a1, float *s_out, con
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
         for (int n = 0; n < NT; ++n) v[0][n][tap] = ap[n][(tap / 3) * 7 + tap % 3];
+#ifdef CRNN_PROBE_NO_GATHER   // timing only: the gathers of channel quads 1.. are replaced by a register
+#define CRNN_GATHER(x) (bias2)
+#else
+#define CRNN_GATHER(x) (x)
+#endif
 #pragma unroll
     for (int cq = 0; cq < G::KQ; ++cq) {
         if (cq + 1 < G::KQ) {
@@ -72,7 +86,7 @@ __device__ __forceinline__ void conv2_tiles(const float *s_a1, float *s_out, con
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    v[(cq + 1) & 1][n][tap] = ap[n][(cq + 1) * 4 * G::CS + (tap / 3) * 7 + tap % 3];  // compile-time offset:imm
+                    v[(cq + 1) & 1][n][tap] = CRNN_GATHER(ap[n][(cq + 1) * 4 * G::CS + (tap / 3) * 7 + tap % 3]);  // compile-time offset:imm
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -82,7 +96,11 @@ __device__ __forceinline__ void conv2_tiles(const float *s_a1, float *s_out, con
                 acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[cq & 1][n][tap], bw2[cq * 9 + tap], acc[n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef CRNN_PROBE_NO_EPI      // timing only: no tile epilogue
+    if (chv && acc[0][0] == 12345.678f) {
+#else
     if (chv) {
+#endif
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -229,7 +247,11 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
     // rewritten only behind the next B2, which every wave reaches after its stream-out.
     park();
     __syncthreads();
+#ifdef CRNN_PROBE_TS
+    int ts_it = 0;
+#endif
     for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        CRNN_TS(0);
         const long row0 = blk * G::RB;
         const int rv = (int)min((long)G::RB, rows - row0);
         float mv = 0.0f;  // vector branch: relu(mlp1([dir_x, dir_y, last-action one-hot])) (base_net.py:66); s_vec is re-parked behind B2
@@ -239,6 +261,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
             for (int k = 0; k < nin; ++k) mv = fmaf(s_vec[mr * G::VEC + k], s_mlp[mc * nin + k], mv);
         }
         fetch(blk + gridDim.x);
+        CRNN_TS(1);
         // ---- conv1
 #ifndef CRNN_PROBE_SKIP_CONV1
         {
@@ -296,8 +319,11 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
             }
         }
 #endif
+        CRNN_TS(2);
         __syncthreads();  // B2
+        CRNN_TS(3);
         park();           // s_in / s_vec were last read before B2
+        CRNN_TS(4);
         // ---- conv2
 #ifndef CRNN_PROBE_SKIP_CONV2
         {
@@ -308,7 +334,9 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
         }
 #endif
         if (mlp_w && tid < G::RB * 10) s_out[mr * G::OUT_STRIDE + OD * 25 + mc] = fmaxf(mv, 0.0f);
+        CRNN_TS(5);
         __syncthreads();  // B3
+        CRNN_TS(6);
         // ---- stream the staged rows out: a wave per row, consecutive lanes on consecutive floats
 #ifndef CRNN_PROBE_SKIP_OUT
         if (wide_out) {  // 8-byte stores: n_out, OUT_STRIDE and (checked once) out / out_stride are even
@@ -324,6 +352,10 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
                 for (int k = lane; k < n_out; k += 64) dst[k] = src[k];
             }
         }
+#endif
+        CRNN_TS(7);
+#ifdef CRNN_PROBE_TS
+        ++ts_it;
 #endif
     }
 }

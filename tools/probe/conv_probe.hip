@@ -1,8 +1,10 @@
-// Standalone timing probe for k_conv9_mfma<24>: build variants with -DCRNN_PROBE_SKIP_* to see which phase costs what.
+// Standalone timing probe for k_conv9_mfma<24>: build variants with -DCRNN_PROBE_SKIP_{CONV1,CONV2,OUT}, -DCRNN_PROBE_NO_GATHER,
+// -DCRNN_PROBE_NO_EPI to see which phase costs what; -DCRNN_PROBE_TS prints per-wave phase stamps of one row block.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "../../marl_dmfb_amd/csrc/crnn_mfma.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 int main(int argc, char **argv) {
@@ -34,5 +36,26 @@ int main(int argc, char **argv) {
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("%s rows %ld: %.1f us/launch\n", argv[0], rows, ms * 1e3 / 20);
+#ifdef CRNN_PROBE_TS
+    {   // phase stamps of the second row block of workgroups 0 and 100: counter ticks relative to the workgroup's earliest loop top
+        unsigned long long *ts; CK(hipMalloc(&ts, (size_t)grid * 8 * 16 * 8)); CK(hipMemset(ts, 0, (size_t)grid * 8 * 16 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(crnn_mfma::g_crnn_ts), &ts, sizeof(ts)));
+        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L, 0,
+                           (const int8_t *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 1);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hts((size_t)grid * 8 * 16); CK(hipMemcpy(hts.data(), ts, hts.size() * 8, hipMemcpyDeviceToHost));
+        const char *names[8] = {"top", "fetch issued", "conv1 done", "B2 passed", "parked", "conv2 done", "B3 passed", "streamed out"};
+        for (int wg : {0, 100}) {
+            if (wg >= grid) continue;
+            unsigned long long t0 = ~0ull; for (int w = 0; w < 8; ++w) t0 = std::min(t0, hts[((size_t)wg * 8 + w) * 16]);
+            printf("workgroup %d, waves 0..7 (wave w runs on SIMD w & 3)\n", wg);
+            for (int k = 0; k < 8; ++k) {
+                printf("  %-13s", names[k]);
+                for (int w = 0; w < 8; ++w) printf(" %7lld", (long long)(hts[((size_t)wg * 8 + w) * 16 + k] - t0));
+                printf("\n");
+            }
+        }
+    }
+#endif
     return 0;
 }
