@@ -328,8 +328,16 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
 #ifndef CRNN_PROBE_SKIP_CONV2
         {
             int t = sub;
+#ifdef CRNN_PROBE_TS
+            int ts_k = 8;
+#endif
 #pragma unroll 1
-            for (; t + 4 < G::T2; t += 8) conv2_tiles<OD, RBV, 2>(s_a1, s_out, bw2, bias2, t, t + 4, j, kq, ch, chv);
+            for (; t + 4 < G::T2; t += 8) {
+                conv2_tiles<OD, RBV, 2>(s_a1, s_out, bw2, bias2, t, t + 4, j, kq, ch, chv);
+#ifdef CRNN_PROBE_TS
+                CRNN_TS(ts_k); ++ts_k;
+#endif
+            }
             if (t < G::T2) conv2_tiles<OD, RBV, 1>(s_a1, s_out, bw2, bias2, t, t, j, kq, ch, chv);
         }
 #endif

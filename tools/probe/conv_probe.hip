@@ -44,12 +44,12 @@ int main(int argc, char **argv) {
                            (const int8_t *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 1);
         CK(hipDeviceSynchronize());
         std::vector<unsigned long long> hts((size_t)grid * 8 * 16); CK(hipMemcpy(hts.data(), ts, hts.size() * 8, hipMemcpyDeviceToHost));
-        const char *names[8] = {"top", "fetch issued", "conv1 done", "B2 passed", "parked", "conv2 done", "B3 passed", "streamed out"};
+        const char *names[11] = {"top", "fetch issued", "conv1 done", "B2 passed", "parked", "conv2 done", "B3 passed", "streamed out", "conv2 pass 1", "conv2 pass 2", "conv2 pass 3"};
         for (int wg : {0, 100}) {
             if (wg >= grid) continue;
             unsigned long long t0 = ~0ull; for (int w = 0; w < 8; ++w) t0 = std::min(t0, hts[((size_t)wg * 8 + w) * 16]);
             printf("workgroup %d, waves 0..7 (wave w runs on SIMD w & 3)\n", wg);
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 11; ++k) {
                 printf("  %-13s", names[k]);
                 for (int w = 0; w < 8; ++w) printf(" %7lld", (long long)(hts[((size_t)wg * 8 + w) * 16 + k] - t0));
                 printf("\n");
