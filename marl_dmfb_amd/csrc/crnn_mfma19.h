@@ -225,6 +225,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv19_mfma(const int8_t *__restric
     const int n_feat = OD * 25 + (mlp_w ? 10 : 0);
     const int n_out = out_cols > n_feat ? out_cols : n_feat;  // columns n_feat .. n_out-1 of a row are written as zeros
     const bool wide_out = (out_stride % 2 == 0) && (((size_t)out) % 8 == 0) && (n_out % 2 == 0);
+    const bool quad_out = (out_stride % 4 == 0) && (((size_t)out) % 16 == 0) && (n_out % 4 == 0) && (G::OUT_STRIDE % 4 == 0);
 
     park();
     for (long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
@@ -293,7 +294,13 @@ __global__ __launch_bounds__(kBlockM) void k_conv19_mfma(const int8_t *__restric
             }
         __syncthreads();
         // ---- stream the staged rows out: a wave per row, consecutive lanes on consecutive floats
-        if (wide_out) {  // 8-byte stores: n_out, OUT_STRIDE and (checked once) out / out_stride are even
+        if (quad_out) {  // 16-byte stores (the padded 640- / 832-column rows of the rollouts and of VDN.learn)
+            for (int rr = wave; rr < rv; rr += kBlockM / 64) {
+                float4 *dst = (float4 *)(out + (row0 + rr) * out_stride);
+                const float4 *src = (const float4 *)(s_out + rr * G::OUT_STRIDE);
+                for (int k = lane; k < n_out / 4; k += 64) dst[k] = src[k];
+            }
+        } else if (wide_out) {  // 8-byte stores: n_out, OUT_STRIDE and (checked once) out / out_stride are even
             for (int rr = wave; rr < rv; rr += kBlockM / 64) {
                 float2 *dst = (float2 *)(out + (row0 + rr) * out_stride);
                 const float2 *src = (const float2 *)(s_out + rr * G::OUT_STRIDE);

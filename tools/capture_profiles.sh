@@ -1,6 +1,6 @@
 #!/bin/bash
 # Capture the measurement records of a round on the MI355X box (run through gpurun from the repo root):
-#   tools/capture_profiles.sh r02 [quick]
+#   tools/capture_profiles.sh r03          (ONLY_BENCH=1 tools/capture_profiles.sh r03: the bench.py sections only)
 # Writes raw rocprofv3 output under gpurun_out/<round>/ (scratch) and the reduced summaries under
 # gpurun_out/<round>/summary/ -- copy those into profiles/<round>/ and profiles/traffic.json and commit them.
 # Counter passes are separate runs with --kernel-trace only (gpurun refuses --pmc combined with other trace domains).
@@ -24,6 +24,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- pyth
 python3 $REPO/tools/reduce_profiles.py trace $OUT/bench_trace $SUM/bench_kernels_by_grid.csv
 cp $(ls $OUT/bench_trace/*/*_kernel_stats.csv | head -1) $SUM/bench_kernel_stats.csv
 
+if [ -n "$ONLY_BENCH" ]; then echo "== ONLY_BENCH: the env-kernel sections are skipped =="; exit 0; fi   # the env kernels did not change
 echo "== env tiers (plain) ==" ; date
 python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 --sizes 4096,65536,262144,655360 --iters 100 --observe > $SUM/env_tiers.jsonl
 cat $SUM/env_tiers.jsonl
