@@ -60,8 +60,21 @@ class Agents:
         first = torch.where(has, t.int().argmax(dim=1), torch.full_like(has, -1, dtype=torch.int64))
         return int(first.max().item()) + 1
 
-    def train(self, batch, train_step, epsilon=None):
-        max_episode_len = self._get_max_episode_len(batch)
+    @staticmethod
+    def first_terminated_bound(terminated):
+        """Device scalar: the `_get_max_episode_len` of a batch, not yet read by the host (train.py reads it together with
+        the round's step count, one transfer)."""
+        t = (terminated[:, :, 0] == 1)
+        has = t.any(dim=1)
+        first = torch.where(has, t.int().argmax(dim=1), torch.full_like(has, -1, dtype=torch.int64))
+        return first.max() + 1
+
+    def train(self, batch, train_step, epsilon=None, max_len=None):
+        """agent/agent.py:63-70.  max_len: an upper bound of `_get_max_episode_len(batch)` the caller already holds on the host
+        (Trainer: the longest episode ever stored in the replay buffer).  The steps between the batch's own length and the bound
+        are padded in every episode of the batch: their TD errors are masked to exact zeros, so loss and gradients are those of
+        the exact length -- and the host does not have to read the length back from the device before it can queue the learn."""
+        max_episode_len = self._get_max_episode_len(batch) if max_len is None else int(max_len)
         for key in batch.keys():
             if key != 'z':
                 batch[key] = batch[key][:, :max_episode_len]

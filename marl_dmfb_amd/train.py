@@ -39,6 +39,7 @@ class Trainer:
             args.fov, args.width, args.length, args.drop_num, args.block_num)
         self.time_steps = 0
         self.trained_times = 0
+        self.len_bound = 0  # longest episode stored so far (first terminated step + 1), kept on the host
         self.dist = bool(self.agents.policy.dist)
         self.rank = torch.distributed.get_rank() if self.dist else 0
         self.saves = []  # (time_steps, evaluate index or None) of every checkpoint written, for tests/logs
@@ -46,9 +47,13 @@ class Trainer:
     def collect_and_learn(self):
         """One round of the outer loop (train.py:59-78).  Returns env steps played this round (this rank)."""
         _, steps, _, success, episode = self.rolloutWorker.generate_episode()
-        played = int((~episode['padded']).sum().item())
+        # ONE device read per round: the steps played and the episode length the learns have to cover
+        played, round_len = (int(v) for v in torch.stack([(~episode['padded']).sum(),
+                                                         Agents.first_terminated_bound(episode['terminated'])]).tolist())
         self.rolloutWorker.note_played(played)  # decides whether the next rollout keeps finished chips out of the Q-network
         self.buffer.store_episode(episode)
+        self.len_bound = max(self.len_bound, round_len)  # >= _get_max_episode_len of any batch sampled from the buffer
+        max_len = self.len_bound if getattr(self.args, 'host_len_bound', True) else None
         local = steps.sum()  # failure-inflated count, as train.py:65
         pol = self.agents.policy
         if self.dist:  # this rank's count travels with the gradients of the first learn (two exactly representable floats)
@@ -62,7 +67,7 @@ class Trainer:
                 # the next learn's sample does not depend on this learn: it is drawn (same generator, same order) while this
                 # learn's gradient all-reduce is in flight instead of after the optimizer step
                 pol.overlap_hook = lambda: prefetched.append(self.buffer.sample(k_batch))
-            self.agents.train(mini_batch, self.trained_times)
+            self.agents.train(mini_batch, self.trained_times, max_len=max_len)
             pol.overlap_hook = None
             self.trained_times += 1
         if self.dist:

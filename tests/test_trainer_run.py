@@ -198,3 +198,37 @@ def test_prefetched_sample_changes_nothing(tmp_path):
     assert got[0]['calls'] == [False, True, True] * 5 and got[1]['calls'] == [False] * 15
     for k, v in got[1]['sd'].items():
         assert torch.equal(got[0]['sd'][k], v), k
+
+
+def test_host_side_length_bound_trains_the_same_weights(tmp_path):
+    """Trainer hands the learns the longest episode length ever stored (kept on the host) instead of reading each sampled
+    batch's own `_get_max_episode_len` back from the device (agent/agent.py:51-61 computes it on the host, from numpy).  The
+    extra steps are padded in every sampled episode, their TD errors masked to zero: same weights up to the order of the
+    sums (the padded terms are exact zeros)."""
+    from marl_dmfb_amd.agent.agent import Agents
+    sds, lens = [], []
+    for bound in (True, False):
+        tr = _trainer(str(tmp_path), 60, host_len_bound=bound, train_time=3)
+        ep = _episode_batch()
+        # make the stored episodes differ in length: cut episodes 1.. short (terminate + pad earlier), keep episode 0 long
+        T_full = Agents._get_max_episode_len(None, {'terminated': ep['terminated']})
+        for e in range(1, ep['terminated'].shape[0]):
+            cut = max(2, T_full // 2 - e)
+            ep['terminated'][e, cut - 1:] = True
+            ep['padded'][e, cut:] = True
+        tr.rolloutWorker.generate_episode = lambda ep=ep: (None, torch.full((6,), 10, dtype=torch.int64), None, None,
+                                                             {k: v.clone() for k, v in ep.items()})
+        seen = []
+        learn = tr.agents.policy.learn
+        tr.agents.policy.learn = lambda batch, T, *a, **k: (seen.append(T), learn(batch, T, *a, **k))[1]
+        det_init(tr.agents.policy.eval_rnn, 3)
+        tr.agents.policy.target_rnn.load_state_dict(tr.agents.policy.eval_rnn.state_dict())
+        for _ in range(4):
+            tr.collect_and_learn()
+        sds.append({k: v.clone() for k, v in tr.agents.policy.eval_rnn.state_dict().items()})
+        lens.append(seen)
+    assert len(lens[0]) == len(lens[1]) == 12
+    assert all(a >= b for a, b in zip(lens[0], lens[1])) and len(set(lens[0])) == 1   # the bound covers every sampled batch
+    assert any(a > b for a, b in zip(lens[0], lens[1]))                              # ... and was really longer for some
+    for k, v in sds[1].items():
+        assert torch.allclose(sds[0][k], v, rtol=1e-5, atol=1e-7), k
