@@ -47,14 +47,15 @@ class Trainer:
     def collect_and_learn(self):
         """One round of the outer loop (train.py:59-78).  Returns env steps played this round (this rank)."""
         _, steps, _, success, episode = self.rolloutWorker.generate_episode()
-        # ONE device read per round: the steps played and the episode length the learns have to cover
-        played, round_len = (int(v) for v in torch.stack([(~episode['padded']).sum(),
-                                                         Agents.first_terminated_bound(episode['terminated'])]).tolist())
+        local = steps.sum()  # failure-inflated count, as train.py:65
+        # ONE device read per round: the steps played, the episode length the learns have to cover, and the step count.  Nothing
+        # else in the round waits for the device (single rank), so the next round's rollout is queued while the learns still run.
+        played, round_len, local_host = (int(v) for v in torch.stack([(~episode['padded']).sum(),
+                                                                     Agents.first_terminated_bound(episode['terminated']), local]).tolist())
         self.rolloutWorker.note_played(played)  # decides whether the next rollout keeps finished chips out of the Q-network
         self.buffer.store_episode(episode)
         self.len_bound = max(self.len_bound, round_len)  # >= _get_max_episode_len of any batch sampled from the buffer
         max_len = self.len_bound if getattr(self.args, 'host_len_bound', True) else None
-        local = steps.sum()  # failure-inflated count, as train.py:65
         pol = self.agents.policy
         if self.dist:  # this rank's count travels with the gradients of the first learn (two exactly representable floats)
             pol.ride_along = torch.stack([local // 4096, local % 4096]).to(torch.float32)
@@ -77,7 +78,7 @@ class Trainer:
             hi, lo = (int(round(v)) for v in pol.ride_along_sum.tolist())
             self.time_steps += hi * 4096 + lo
         else:
-            self.time_steps += int(local.item())
+            self.time_steps += local_host
         return played
 
     def _evaluate_and_record(self, evaluator=None):
