@@ -44,6 +44,23 @@ int vdn_td_forward(const float *d_q_eval, const float *d_q_target, const int8_t 
 int vdn_td_backward(const float *d_mtd, const float *d_mask, const int8_t *d_u, const float *d_grad_num, int32_t B, int32_t T,
                     int32_t t_limit, int32_t n_agents, int32_t n_actions, float *d_grad_q, void *stream);
 
+/* The tail of VDN.learn (policy/vdn.py:125-127): torch.nn.utils.clip_grad_norm_(eval_parameters, max_norm) followed by
+ * optimizer.step() of torch.optim.Adam(lr, betas) (policy/vdn.py:67-68), for up to VDN_MAX_TENSORS float32 parameter tensors,
+ * in two launches instead of the ~11 of the foreach / fused torch path:
+ *   total = sqrt(sum over all tensors of sum(g^2));  c = min(1, max_norm / (total + 1e-6));  g' = g * c
+ *   m = m + (1 - beta1) * (g' - m);  v = beta2 * v + (1 - beta2) * g' * g';
+ *   p -= (lr / bias_correction1) * m / (sqrt(v) / sqrt(bias_correction2) + eps)
+ * (torch's formulas; bias_correction = 1 - beta^step is computed by the caller; the scalars are doubles and enter the float
+ * element arithmetic where torch's do: 1 - beta and lr / bias_correction1 rounded to float once, the denominator formed in double).  The gradients are rescaled in memory as well
+ * (clip_grad_norm_ leaves g' in p.grad).  d_partials: VDN_NORM_BLOCKS floats of scratch;
+ * *d_total_norm receives `total` (the value clip_grad_norm_ returns).  The pointer arrays are HOST arrays of DEVICE pointers. */
+#define VDN_MAX_TENSORS 32
+#define VDN_NORM_BLOCKS 128
+int vdn_clip_adam_step(int32_t n_tensors, float *const *params, float *const *grads, float *const *exp_avg,
+                       float *const *exp_avg_sq, const int64_t *numel, float max_norm, double lr, double beta1, double beta2,
+                       double eps, double bias_correction1, double bias_correction2, float *d_partials, float *d_total_norm,
+                       void *stream);
+
 int vdn_last_hip_error(void);
 
 #ifdef __cplusplus

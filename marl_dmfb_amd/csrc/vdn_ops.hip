@@ -59,7 +59,111 @@ __global__ __launch_bounds__(256) void k_td_backward(const float *__restrict__ m
 
 }  // namespace
 
+namespace {
+
+// ---- clip_grad_norm_ + Adam over a list of tensors (include/vdn_ops.h)
+struct TensorList {
+    float *p[VDN_MAX_TENSORS];
+    float *g[VDN_MAX_TENSORS];
+    float *m[VDN_MAX_TENSORS];
+    float *v[VDN_MAX_TENSORS];
+    long off[VDN_MAX_TENSORS + 1];  // prefix sums of the element counts
+    int n;
+};
+
+// element i of the concatenation -> (tensor k, index inside it); i only grows along a thread's walk, so k is carried along
+__device__ __forceinline__ void locate(const TensorList &tl, long i, int &k) {
+    while (i >= tl.off[k + 1]) ++k;
+}
+
+__global__ __launch_bounds__(256) void k_sqnorm_partials(TensorList tl, float *__restrict__ partials) {
+    __shared__ float s_w[4];
+    const long total = tl.off[tl.n];
+    const long per = (total + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * per, hi = min(total, lo + per);
+    float acc = 0.0f;
+    int k = 0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        locate(tl, i, k);
+        const float g = tl.g[k][i - tl.off[k]];
+        acc = fmaf(g, g, acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ __launch_bounds__(256) void k_clip_adam(TensorList tl, const float *__restrict__ partials, int n_partials, float max_norm,
+                                                   float step_size, float omb1, float beta2, float omb2, double eps, double bc2_sqrt,
+                                                   float *__restrict__ total_norm) {
+    __shared__ float s_coef;
+    if (threadIdx.x < 64) {  // every workgroup adds the partial sums in the same fixed order
+        float t = 0.0f;
+        for (int b = threadIdx.x; b < n_partials; b += 64) t += partials[b];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (threadIdx.x == 0) {
+            const float norm = sqrtf(t);
+            s_coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
+            if (blockIdx.x == 0) total_norm[0] = norm;
+        }
+    }
+    __syncthreads();
+    const float coef = s_coef;
+    const long total = tl.off[tl.n];
+    const long per = (total + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * per, hi = min(total, lo + per);
+    int k = 0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        locate(tl, i, k);
+        const long j = i - tl.off[k];
+        const float g = tl.g[k][j] * coef;
+        if (coef != 1.0f) tl.g[k][j] = g;  // clip_grad_norm_ leaves the rescaled gradient in p.grad
+        float m = tl.m[k][j], v = tl.v[k][j];
+        m = m + omb1 * (g - m);
+        v = beta2 * v + omb2 * g * g;
+        tl.m[k][j] = m;
+        tl.v[k][j] = v;
+        const float denom = (float)((double)sqrtf(v) / bc2_sqrt + eps);  // torch forms the denominator with double scalars
+        tl.p[k][j] -= step_size * m / denom;
+    }
+}
+
+}  // namespace
+
 extern "C" {
+
+int vdn_clip_adam_step(int32_t n_tensors, float *const *params, float *const *grads, float *const *exp_avg,
+                       float *const *exp_avg_sq, const int64_t *numel, float max_norm, double lr, double beta1, double beta2,
+                       double eps, double bias_correction1, double bias_correction2, float *d_partials, float *d_total_norm,
+                       void *stream) {
+    if (n_tensors < 1 || n_tensors > VDN_MAX_TENSORS || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !d_partials ||
+        !d_total_norm || !(bias_correction1 > 0.0) || !(bias_correction2 > 0.0))
+        return VDN_ERR_BAD_ARG;
+    TensorList tl;
+    tl.n = n_tensors;
+    tl.off[0] = 0;
+    for (int k = 0; k < VDN_MAX_TENSORS; ++k) {
+        const bool on = k < n_tensors;
+        if (on && (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k] || numel[k] < 1)) return VDN_ERR_BAD_ARG;
+        tl.p[k] = on ? params[k] : nullptr;
+        tl.g[k] = on ? grads[k] : nullptr;
+        tl.m[k] = on ? exp_avg[k] : nullptr;
+        tl.v[k] = on ? exp_avg_sq[k] : nullptr;
+        tl.off[k + 1] = tl.off[k] + (on ? (long)numel[k] : 0);
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_sqnorm_partials, dim3(VDN_NORM_BLOCKS), dim3(256), 0, (hipStream_t)stream, tl, d_partials);
+    const long total = tl.off[n_tensors];
+    const int blocks = (int)((total + 1023) / 1024 < 1024 ? (total + 1023) / 1024 : 1024);
+    hipLaunchKernelGGL(k_clip_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tl, d_partials, VDN_NORM_BLOCKS, max_norm,
+                       (float)((double)lr / bias_correction1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (double)eps,
+                       sqrt(bias_correction2), d_total_norm);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last = (int)e; return VDN_ERR_HIP; }
+    return VDN_OK;
+}
+
 
 int vdn_td_forward(const float *d_q_eval, const float *d_q_target, const int8_t *d_u, const float *d_r,
                    const int8_t *d_avail_next, const uint8_t *d_terminated, const uint8_t *d_padded, int32_t B, int32_t T,

@@ -154,6 +154,7 @@ class VDN:
         self.last_loss = None
         self.last_grad_norm = None
         self._flat = None
+        self._adam = None  # moments and step count of the two-launch clip + Adam step (_fused_step)
         self._td_bad = None  # device counter of (episode, step) slots whose action was outside [0, n_actions) (include/vdn_ops.h)
         # scalars a caller wants summed over the ranks without a collective of their own (Trainer: the env-step count of the
         # round): float32 tensor set before learn(); the next gradient all-reduce carries it and leaves the sums here
@@ -298,10 +299,52 @@ class VDN:
                 self._td_bad.zero_()
                 raise RuntimeError('VDN.learn: %d (episode, step) slots with an action outside [0, %d)' % (bad, self.n_actions))
 
+    def _fused_step(self):
+        """clip_grad_norm_ + Adam.step as two launches (include/vdn_ops.h: vdn_clip_adam_step) instead of torch's ~11 small
+        ones; same formulas.  Returns False (torch path) when it does not apply: not the GPU Adam of policy/vdn.py:67-68, a
+        non-float32 / non-contiguous tensor, more tensors than the C ABI takes.  The moments live here, not in
+        self.optimizer.state (the reference never saves optimizer state: policy/vdn.py:167-174)."""
+        a = self.args
+        if not (self.device.type == 'cuda' and a.optimizer == 'ADAM' and getattr(a, 'fused_clip_adam', True)):
+            return False
+        params = [p for p in self.eval_parameters if p.grad is not None]
+        if not params or len(params) > 32:
+            return False
+        for p in params:
+            if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                return False
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.vdn_ops()
+        st = self._adam
+        if st is None:
+            st = self._adam = {'step': 0, 'm': {}, 'v': {}, 'partials': torch.empty(128, dtype=torch.float32, device=self.device),
+                               'norm': torch.zeros(1, dtype=torch.float32, device=self.device)}
+        for p in params:
+            if id(p) not in st['m']:
+                st['m'][id(p)] = torch.zeros_like(p)
+                st['v'][id(p)] = torch.zeros_like(p)
+        st['step'] += 1
+        group = self.optimizer.param_groups[0]
+        b1, b2 = group['betas']
+        n = len(params)
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        numel = (C.c_int64 * n)(*[p.numel() for p in params])
+        rc = lib.vdn_clip_adam_step(n, arr(params), arr([p.grad for p in params]), arr([st['m'][id(p)] for p in params]),
+                                    arr([st['v'][id(p)] for p in params]), numel, float(a.grad_norm_clip), float(group['lr']),
+                                    float(b1), float(b2), float(group['eps']), 1.0 - b1 ** st['step'], 1.0 - b2 ** st['step'],
+                                    C.c_void_p(st['partials'].data_ptr()), C.c_void_p(st['norm'].data_ptr()),
+                                    C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('vdn_clip_adam_step failed: %d (hip %d)' % (rc, lib.vdn_last_hip_error()))
+        self.last_grad_norm = st['norm'][0]
+        return True
+
     def _step_and_sync(self, loss, train_step):
         """clip_grad_norm_, optimizer step, hard target sync every target_update_cycle learns (policy/vdn.py:125-132)."""
-        self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.eval_parameters, self.args.grad_norm_clip)
-        self.optimizer.step()
+        if not self._fused_step():
+            self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.eval_parameters, self.args.grad_norm_clip)
+            self.optimizer.step()
         self.last_loss = loss.detach()
 
         if train_step > 0 and train_step % self.args.target_update_cycle == 0:

@@ -116,9 +116,11 @@ def test_vdn_ops_library_exports():
     txt = open(os.path.join(ROOT, 'include', 'vdn_ops.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     names = sorted(set(re.findall(r'\b(vdn_[a-z_0-9]+)\s*\(', txt)))
-    assert names == ['vdn_last_hip_error', 'vdn_td_backward', 'vdn_td_forward']
+    assert names == ['vdn_clip_adam_step', 'vdn_last_hip_error', 'vdn_td_backward', 'vdn_td_forward']
     for n in names:
         assert hasattr(lib, n)
     # argument guards run on the host before anything touches the GPU
     assert lib.vdn_td_forward(None, None, None, None, None, None, None, 4, 3, 8, 2, 5, 0.99, None, None, None, None) == -1
+    assert lib.vdn_clip_adam_step(0, None, None, None, None, None, 10.0, 1e-3, 0.9, 0.99, 1e-8, 0.1, 0.01, None, None, None) == -1
+    assert lib.vdn_clip_adam_step(33, None, None, None, None, None, 10.0, 1e-3, 0.9, 0.99, 1e-8, 0.1, 0.01, None, None, None) == -1
     assert lib.vdn_td_backward(None, None, None, None, 4, 3, 8, 2, 5, None, None) == -1

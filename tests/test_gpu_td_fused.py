@@ -127,3 +127,70 @@ def test_action_outside_range_is_loud_not_out_of_bounds():
     with pytest.raises(RuntimeError, match='outside'):
         tr.agents.policy.save_model(0)
     tr.agents.policy.check_td_inputs()   # the counter was cleared by the raise
+
+
+@pytest.mark.parametrize('clip', [1.0e6, 0.05])
+def test_two_launch_clip_and_adam_equals_torch_clip_and_adam(clip):
+    """vdn_clip_adam_step (include/vdn_ops.h) against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step
+    (policy/vdn.py:125-127 with the optimizer of :67-68), ONE step at a time from identical parameters, moments and gradients
+    (the network's tensor shapes; gradients from 1e-12 to 1 in magnitude; six steps, so the bias corrections move): the returned
+    norm (rtol 1e-5: another summation order) and every updated parameter and moment (the update within 2e-6 of its own size +
+    one ulp of the parameter).  clip 0.05 makes the clip coefficient bite on every step, clip 1e6 leaves it at 1.  The two are not
+    compared over a free-running sequence of learns: where a gradient element is at noise level m / (sqrt(v) + eps) turns
+    last-bit differences into a visible fraction of a step and the gap grows with the steps (measured: 1 element of 5184
+    off by 1.7e-6 after two learns, 6 after four)."""
+    tr = _trainer('dmfb')
+    pol = tr.agents.policy
+    pol.args = copy.copy(pol.args)
+    pol.args.grad_norm_clip = clip
+    params = pol.eval_parameters
+    refs = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    opt = torch.optim.Adam(refs, lr=pol.args.lr, betas=(0.9, 0.99), fused=True)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    for step in range(6):
+        for p, r in zip(params, refs):
+            mag = 10.0 ** torch.empty_like(p).uniform_(-12.0, 0.0, generator=gen)
+            g = mag * torch.sign(torch.randn(p.shape, device=p.device, generator=gen))
+            p.grad = g.clone()
+            r.grad = g.clone()
+        before = [r.detach().clone() for r in refs]
+        want_norm = torch.nn.utils.clip_grad_norm_(refs, clip)
+        opt.step()
+        assert pol._fused_step()
+        np.testing.assert_allclose(float(pol.last_grad_norm), float(want_norm), rtol=1e-5)
+        assert (float(want_norm) > clip) == (clip < 1.0)
+        for k, (p, r, b) in enumerate(zip(params, refs, before)):
+            tol = 2e-6 * (r.detach() - b).abs() + 1.2e-7 * r.detach().abs() + 1e-9   # + one ulp of the parameter itself
+            assert bool(((p.detach() - r.detach()).abs() <= tol).all()), (k, step, float((p.detach() - r.detach()).abs().max()))
+            st = opt.state[r]
+            # m = m + 0.1 (g - m) cancels where g ~ m: its error is measured against the operands, v is a sum of positives
+            err_m = (pol._adam['m'][id(p)] - st['exp_avg']).abs() / (st['exp_avg'].abs() + 0.2 * r.grad.abs()).clamp_min(1e-37)
+            err_v = (pol._adam['v'][id(p)] - st['exp_avg_sq']).abs() / st['exp_avg_sq'].abs().clamp_min(1e-37)
+            assert float(err_m.max()) <= 1e-6 and float(err_v.max()) <= 1e-6, (k, step, float(err_m.max()), float(err_v.max()))
+            # next step from identical state
+            p.data.copy_(r.data)
+            pol._adam['m'][id(p)].copy_(st['exp_avg'])
+            pol._adam['v'][id(p)].copy_(st['exp_avg_sq'])
+
+
+def test_learns_with_the_two_launch_step_track_the_torch_step():
+    """Free-running: five learns with vdn_clip_adam_step against five with torch's clip + Adam, same batches.  Loose by design
+    (see the test above): gradient norms within 1e-3, every weight within 5 % of the Adam steps taken."""
+    tr = _trainer('dmfb')
+    for _ in range(2):
+        tr.buffer.store_episode(tr.rolloutWorker.generate_episode()[4])
+    pol = tr.agents.policy
+    ref = copy.deepcopy(pol)
+    ref.args = copy.copy(pol.args)
+    ref.args.fused_clip_adam = False
+    for step in range(5):
+        batch = tr.buffer.sample(64)
+        batch_ref = {k: v.clone() for k, v in batch.items()}
+        tr.agents.train(batch, step)
+        lb = copy.copy(tr.agents)
+        lb.policy = ref
+        lb.train(batch_ref, step)
+        assert pol._adam is not None and pol._adam['step'] == step + 1 and ref._adam is None
+        np.testing.assert_allclose(float(pol.last_grad_norm), float(ref.last_grad_norm), rtol=1e-3)
+        for (ka, pa), (kb, pb) in zip(pol.eval_rnn.state_dict().items(), ref.eval_rnn.state_dict().items()):
+            assert float((pa - pb).abs().max()) <= 0.05 * 5e-4 * (step + 1), (ka, step)
