@@ -26,6 +26,7 @@ namespace {
 
 constexpr int kBlock = 512;  // 8 waves: one workgroup per CU keeps ONE copy of the weights in LDS for 2 waves per SIMD
 constexpr int kA1Stride = 52;  // 49 conv1 activations per (row, channel), padded to a 16-byte multiple
+constexpr int kDz1Unit = 108;  // dz1 of a (row, channel pair): 2 x 49 floats interleaved, padded (16-byte multiple, 108 mod 32 = 12)
 
 constexpr int kLdsBudget = 158 * 1024;  // of the CU's 160 KiB
 
@@ -35,12 +36,12 @@ constexpr int kLdsBudget = 158 * 1024;  // of the CU's 160 KiB
 // them once to part[blockIdx][...]; the host adds the <= 256 partial vectors (deterministic, no atomics).
 //   P0  stage a1 (saved by the forward), dz2 = g * (a2 > 0) and the float input rows in LDS
 //   P1  dW2[c2][c1][tap] += sum_pos dz2[c2][pos] * a1[c1][pos + tap]         thread = (c2, c1) pair(s)
-//   P2  da1[c1][p] = sum_c2,tap dz2[c2][p - tap] * W2[c2][c1][tap]; dz1 = da1 * (a1 > 0)   thread = (row, c1, half of c2)
+//   P2  da1[c1][p] = sum_c2,tap dz2[c2][p - tap] * W2[c2][c1][tap]; dz1 = da1 * (a1 > 0)   lane quad = (row, channel pair), lane = quarter of c2
 //   P3  dW1[c1][c0][tap] += sum_pos dz1[c1][pos] * in[c0][pos + tap]          thread = (c1, c0, tap) item(s)
 template <int OD> struct GeoB {
     static constexpr int DZ2 = 28;  // 25 padded to a 16-byte multiple
     static constexpr int DZ_ROW = OD * DZ2 + 4;  // +4 words: OD*28 is a multiple of the 32 LDS banks, and P2's lanes span rows
-    static constexpr int ROW_FLOATS = OD * kA1Stride + OD * DZ2 + 4 + 244 + OD * kA1Stride;  // a1, dz2 (+4 pad), in, dz1/da1 partial
+    static constexpr int ROW_FLOATS = OD * kA1Stride + OD * DZ2 + 4 + 244 + (OD / 2) * kDz1Unit;  // a1, dz2 (+4 pad), in, dz1
     static constexpr int FIXED_FLOATS = OD * OD * 9;
     static constexpr int RBB = ((kLdsBudget / 4 - FIXED_FLOATS) / ROW_FLOATS) < (kBlock / (2 * OD)) ? ((kLdsBudget / 4 - FIXED_FLOATS) / ROW_FLOATS)
                                                                                                    : (kBlock / (2 * OD));
@@ -71,8 +72,8 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     float *s_a1 = s_w2 + OD * OD * 9;                   // [RBB][OD][52]
     float *s_dz2 = s_a1 + G::RBB * OD * kA1Stride;      // [RBB][OD][28]
     float *s_in = s_dz2 + G::RBB * G::DZ_ROW;            // [RBB][244]
-    float *s_dz1 = s_in + G::RBB * 244;                 // [RBB][OD][52]
-    float *s_w1 = s_dz1 + G::RBB * OD * kA1Stride;      // [OD][27] conv1 weights, then [OD] biases
+    float *s_dz1 = s_in + G::RBB * 244;                 // [RBB][OD/2][108]: dz1 of a channel pair, interleaved
+    float *s_w1 = s_dz1 + G::RBB * (OD / 2) * kDz1Unit; // [OD][27] conv1 weights, then [OD] biases
     const int tid = threadIdx.x;
     for (int i = tid; i < OD * 27; i += kBlock) s_w1[i] = w1[i];
     if (tid < OD) s_w1[OD * 27 + tid] = b1[tid];
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         const int c2 = i / (OD * 9), rem = i - c2 * OD * 9, c1 = rem / 9, tap = rem - c1 * 9;
         s_w2[(c2 * 9 + tap) * OD + c1] = w2[i];
     }
-    float accA[9], accX[9], accW1[3], accB2 = 0.0f, accB1 = 0.0f;  // persistent over all rows of the workgroup
+    float accA[9], accX[9], accW1[3], accB2 = 0.0f, accB1 = 0.0f, accB1y = 0.0f;  // persistent over all rows of the workgroup
 #pragma unroll
     for (int k = 0; k < 9; ++k) { accA[k] = 0.0f; accX[k] = 0.0f; }
 #pragma unroll
@@ -96,9 +97,11 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     const bool p3_on = s3 < G::RS3;
     const int c1_3 = i3 / 9, c0_3 = (i3 - c1_3 * 9) / 3, kx_3 = i3 - c1_3 * 9 - c0_3 * 3;
 
-    // P2 role: (half of the c2 range, row r2, channel c1b); the half-0 threads also own the bias sums of (row r2, channel c1b)
-    const int half = tid / (G::RBB * OD), rem2 = tid - half * G::RBB * OD;
-    const int r2 = rem2 / OD, c1b = rem2 - r2 * OD;
+    // P2 role: lane quad = (row r2, channel PAIR cp), lane q of the quad = a quarter of the c2 range.  db2 role: thread (row br,
+    // channel bc) of the first RBB * OD threads.
+    const int q2 = tid & 3, unit2 = tid >> 2;
+    const int r2 = unit2 / (OD / 2), cp2 = unit2 - r2 * (OD / 2);
+    const int br = tid / OD, bc = tid - br * OD;
 
     const long n_blocks = (rows + G::RBB - 1) / G::RBB;
     const long per = (n_blocks + gridDim.x - 1) / gridDim.x;
@@ -227,10 +230,10 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
                                 acc[kx * 3 + ky] = fmaf(dz[x * 5 + y], a[(x + kx) * 7 + y + ky], acc[kx * 3 + ky]);
             }
         };
-        // db2[c2] += sum of dz2[row][c2][.]: thread (row, c2) = the (r2, c1b) role of P2.  Inside pair_rows (the thread of pair
-        // (c2, 0) has the row's dz2 in registers) the 25 adds ran in every wave for one lane in 24.
-        if (tid < G::RBB * OD && r2 < rv) {
-            const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + r2 * G::DZ_ROW + c1b * G::DZ2, 16);
+        // db2[c2] += sum of dz2[row][c2][.]: thread (row br, channel bc).  Inside pair_rows (the thread of pair (c2, 0) has the
+        // row's dz2 in registers) the 25 adds ran in every wave for one lane in 24.
+        if (tid < G::RBB * OD && br < rv) {
+            const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + br * G::DZ_ROW + bc * G::DZ2, 16);
             float t = 0.0f;
 #pragma unroll
             for (int j = 0; j < 6; ++j) { const float4 v = pd[j]; t += (v.x + v.y) + (v.z + v.w); }
@@ -240,24 +243,33 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         if (pa_on) pair_rows(pa_c2, pa_c1, 0, 1, accA);
         if (px_on) pair_rows(px_c2, px_c1, px_slice, (G::EXTRA == kBlock) ? 1 : G::XSLICES, accX);
 #endif
-        // ---- P2: da1 partial sums over half of the c2 range; half 1 parks its partial in s_dz1
+        // ---- P2: da1[c1][p] = sum over c2, tap of dz2[c2][p - tap] * W2[c2][c1][tap];  dz1 = da1 * (a1 > 0).
+        // A thread owns TWO channels (c1 = 2 cp, 2 cp + 1) of one row and a quarter of the c2 range: every multiply-add is a
+        // v_pk_fma_f32 on a natural register pair -- (da[p] of both channels) += dz2 (broadcast) * (W2 of both channels, adjacent
+        // in the [c2][tap][c1] LDS copy).  With one channel per thread the compiler packed neighbouring positions instead and
+        // spent 155 register moves per 135 multiply-adds on lining the pairs up.  The four quarter sums of a quad meet through
+        // DPP (no LDS, no barrier); lane 0 of the quad applies the ReLU mask and writes dz1, pair-interleaved:
+        // s_dz1[(row * OD/2 + cp) * kDz1Unit + 2 * position + (c1 & 1)]  (kDz1Unit = 108: P3's eight channel pairs per wave on
+        // eight different bank groups).
 #ifndef CRNN_PROBE_SKIP_P2
-        const bool p2 = half < 2 && r2 < rv;
+        const bool p2 = unit2 < G::RBB * (OD / 2) && r2 < rv;
 #else
         const bool p2 = false;
 #endif
-        float da[49];
         if (p2) {
+            float2 da[49];
 #pragma unroll
-            for (int k = 0; k < 49; ++k) da[k] = 0.0f;
-            const int cbeg = half * (OD / 2), cend = cbeg + OD / 2;
+            for (int k = 0; k < 49; ++k) da[k] = make_float2(0.0f, 0.0f);
+            const int cbeg = q2 * (OD / 4), cend = cbeg + OD / 4;
+#pragma unroll 1
             for (int c2 = cbeg; c2 < cend; ++c2) {
-                float dz[G::DZ2], w[9];
+                float dz[G::DZ2];
+                float2 w[9];
                 const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + r2 * G::DZ_ROW + c2 * G::DZ2, 16);
 #pragma unroll
                 for (int j = 0; j < G::DZ2 / 4; ++j) { const float4 t = pd[j]; dz[4 * j] = t.x; dz[4 * j + 1] = t.y; dz[4 * j + 2] = t.z; dz[4 * j + 3] = t.w; }
 #pragma unroll
-                for (int k = 0; k < 9; ++k) w[k] = s_w2[(c2 * 9 + k) * OD + c1b];
+                for (int k = 0; k < 9; ++k) w[k] = *(const float2 *)(s_w2 + (c2 * 9 + k) * OD + 2 * cp2);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -265,41 +277,60 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
 #pragma unroll
                         for (int x = 0; x < 5; ++x)
 #pragma unroll
-                            for (int y = 0; y < 5; ++y)
-                                da[(x + kx) * 7 + y + ky] = fmaf(dz[x * 5 + y], w[kx * 3 + ky], da[(x + kx) * 7 + y + ky]);
+                            for (int y = 0; y < 5; ++y) {
+                                float2 &d = da[(x + kx) * 7 + y + ky];
+                                const float z = dz[x * 5 + y];
+                                d.x = fmaf(z, w[kx * 3 + ky].x, d.x);
+                                d.y = fmaf(z, w[kx * 3 + ky].y, d.y);
+                            }
             }
-            if (half == 1) {
-                float4 *dst4 = (float4 *)__builtin_assume_aligned(s_dz1 + (r2 * OD + c1b) * kA1Stride, 16);
+            // quad sum: lanes q ^ 1, then q ^ 2 (quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E); whole quads are active or not
+#ifndef CRNN_PROBE_P2_NO_DPP
+            // one v_add_f32_dpp per value and step (the builtin became v_mov_dpp x 2 + v_pk_add through two shared temporaries:
+            // a serial chain).  All of step 1 first, then all of step 2: a DPP operand must not have been written by the
+            // instruction just before it, and the compiler does not look into the asm for that.
 #pragma unroll
-                for (int j = 0; j < 12; ++j) dst4[j] = make_float4(da[4 * j], da[4 * j + 1], da[4 * j + 2], da[4 * j + 3]);
-                dst4[12] = make_float4(da[48], 0.0f, 0.0f, 0.0f);
+            for (int k = 0; k < 49; ++k) {
+                asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(da[k].x));
+                asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(da[k].y));
             }
-        }
-        __syncthreads();
-        if (p2 && half == 0) {
-            // dz1 = (da1 of both c2 halves) * (a1 > 0): all loads first (the ReLU mask as bits, then the other half's partial
-            // sums), selects, 16-byte stores.  Element by element the compiler kept load -> compare -> branch -> load -> store in
-            // order (the two LDS arrays may alias for all it knows): 98 LDS round trips one after the other per row block.
-            float4 *dst4 = (float4 *)__builtin_assume_aligned(s_dz1 + (r2 * OD + c1b) * kA1Stride, 16);
-            const float4 *act4 = (const float4 *)__builtin_assume_aligned(s_a1 + (r2 * OD + c1b) * kA1Stride, 16);
-            unsigned long long live = 0;
+            asm volatile("s_nop 1");
 #pragma unroll
-            for (int j = 0; j < 13; ++j) {
-                const float4 a = act4[j];
-                live |= (unsigned long long)((a.x > 0.0f ? 1u : 0u) | (a.y > 0.0f ? 2u : 0u) | (a.z > 0.0f ? 4u : 0u) | (a.w > 0.0f ? 8u : 0u)) << (4 * j);
+            for (int k = 0; k < 49; ++k) {
+                asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(da[k].x));
+                asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(da[k].y));
             }
-            float4 other[13];
+#endif
+#ifdef CRNN_PROBE_P2_NO_MASK
+            if (q2 == 0 && da[0].x == 12345.678f) {
+#else
+            if (q2 == 0) {
+#endif
+                // ReLU mask of both channels as bits (vector loads first), then selects and 16-byte stores of two positions each
+                const float4 *actx = (const float4 *)__builtin_assume_aligned(s_a1 + (r2 * OD + 2 * cp2) * kA1Stride, 16);
+                const float4 *acty = actx + kA1Stride / 4;
+                unsigned long long lx = 0, ly = 0;
 #pragma unroll
-            for (int j = 0; j < 13; ++j) other[j] = dst4[j];
+                for (int j = 0; j < 13; ++j) {
+                    const float4 a = actx[j], b = acty[j];
+                    lx |= (unsigned long long)((a.x > 0.0f ? 1u : 0u) | (a.y > 0.0f ? 2u : 0u) | (a.z > 0.0f ? 4u : 0u) | (a.w > 0.0f ? 8u : 0u)) << (4 * j);
+                    ly |= (unsigned long long)((b.x > 0.0f ? 1u : 0u) | (b.y > 0.0f ? 2u : 0u) | (b.z > 0.0f ? 4u : 0u) | (b.w > 0.0f ? 8u : 0u)) << (4 * j);
+                }
+                float4 *dst4 = (float4 *)__builtin_assume_aligned(s_dz1 + (size_t)unit2 * kDz1Unit, 16);
+                float sx = 0.0f, sy = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 13; ++j) {
-                float4 o;
-                o.x = (live >> (4 * j)) & 1 ? da[4 * j] + other[j].x : 0.0f;
-                o.y = (4 * j + 1 < 49 && ((live >> (4 * j + 1)) & 1)) ? da[4 * j + 1 < 49 ? 4 * j + 1 : 0] + other[j].y : 0.0f;
-                o.z = (4 * j + 2 < 49 && ((live >> (4 * j + 2)) & 1)) ? da[4 * j + 2 < 49 ? 4 * j + 2 : 0] + other[j].z : 0.0f;
-                o.w = (4 * j + 3 < 49 && ((live >> (4 * j + 3)) & 1)) ? da[4 * j + 3 < 49 ? 4 * j + 3 : 0] + other[j].w : 0.0f;
-                dst4[j] = o;
-                accB1 += (o.x + o.y) + (o.z + o.w);  // db1[c1b] += sum of dz1[r2][c1b][.]
+                for (int j = 0; j < 25; ++j) {  // positions 2j, 2j + 1 (position 49 does not exist: zeros)
+                    float4 o;
+                    o.x = (lx >> (2 * j)) & 1 ? da[2 * j].x : 0.0f;
+                    o.y = (ly >> (2 * j)) & 1 ? da[2 * j].y : 0.0f;
+                    o.z = (2 * j + 1 < 49 && ((lx >> (2 * j + 1)) & 1)) ? da[2 * j + 1 < 49 ? 2 * j + 1 : 0].x : 0.0f;
+                    o.w = (2 * j + 1 < 49 && ((ly >> (2 * j + 1)) & 1)) ? da[2 * j + 1 < 49 ? 2 * j + 1 : 0].y : 0.0f;
+                    dst4[j] = o;
+                    sx += o.x + o.z;
+                    sy += o.y + o.w;
+                }
+                accB1 += sx;   // db1[2 cp]     += sum of dz1[r2][2 cp][.]
+                accB1y += sy;  // db1[2 cp + 1]
             }
         }
         __syncthreads();
@@ -313,13 +344,13 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
             for (int rr = s3; rr < rv; rr += G::RS3) {
                 // one 7-wide line of dz1 at a time: the whole 7x7 plane in registers (52) next to the prefetched block (29)
                 // went over the register file and the tail of the prefetch was spilled load by load
-                const float *pd = s_dz1 + (rr * OD + c1_3) * kA1Stride;
+                const float *pd = s_dz1 + (size_t)(rr * (OD / 2) + (c1_3 >> 1)) * kDz1Unit + (c1_3 & 1);  // pair-interleaved (P2)
                 const float *in = s_in + rr * 244 + c0_3 * 81 + kx_3 * 9;
 #pragma unroll
                 for (int x = 0; x < 7; ++x) {
                     float dz[7], v[9];
 #pragma unroll
-                    for (int y = 0; y < 7; ++y) dz[y] = pd[x * 7 + y];
+                    for (int y = 0; y < 7; ++y) dz[y] = pd[2 * (x * 7 + y)];
 #pragma unroll
                     for (int y = 0; y < 9; ++y) v[y] = in[x * 9 + y];
 #pragma unroll
@@ -330,12 +361,13 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
             }
         }
     }
-    // bias gradients: thread (r2, c) of the first RBB * OD holds the sums of its row slot for db1[c] and db2[c]; the RBB slots of
-    // a channel meet in LDS and are added in a fixed order
+    // bias gradients: thread (br, bc) holds db2's sum of its row slot, lane 0 of quad (r2, cp) db1's of its two channels; the RBB
+    // slots of a channel meet in LDS and are added in a fixed order
     __syncthreads();
-    if (tid < G::RBB * OD) {
-        s_dz2[c1b * 16 + r2] = accB1;
-        s_dz2[OD * 16 + c1b * 16 + r2] = accB2;
+    if (tid < G::RBB * OD) s_dz2[OD * 16 + bc * 16 + br] = accB2;
+    if (q2 == 0 && unit2 < G::RBB * (OD / 2)) {
+        s_dz2[(2 * cp2) * 16 + r2] = accB1;
+        s_dz2[(2 * cp2 + 1) * 16 + r2] = accB1y;
     }
     __syncthreads();
     float *pp = part + (size_t)blockIdx.x * G::PART;
