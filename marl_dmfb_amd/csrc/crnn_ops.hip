@@ -52,10 +52,10 @@ template <int OD> struct GeoB {
     static constexpr int EXTRA = PAIRS - kBlock;
     static constexpr int XSLICES = EXTRA > 0 ? kBlock / EXTRA : 1;
     // dW1 work items (c1, c0, kx) x row slices
-    static constexpr int ITEMS3 = OD * 9;
-    static constexpr int RS3 = kBlock / ITEMS3;  // 2 (od 24) or 1 (od 32)
-    // partial vector: dW2 first pass [kBlock][9] | dW2 extra [kBlock][9] | db2 [OD] | dW1 [kBlock][3] | db1 [OD]
-    static constexpr int PART = kBlock * 9 + kBlock * 9 + OD + kBlock * 3 + OD;
+    static constexpr int ITEMS3 = (OD / 2) * 9;  // (channel PAIR, c0, kx)
+    static constexpr int RS3 = kBlock / ITEMS3;  // 4 (od 24) or 3 (od 32)
+    // partial vector: dW2 first pass [kBlock][9] | dW2 extra [kBlock][9] | db2 [OD] | dW1 [kBlock][2 channels][3] | db1 [OD]
+    static constexpr int PART = kBlock * 9 + kBlock * 9 + OD + kBlock * 6 + OD;
 };
 
 // Nothing is saved by the forward: the conv1 activations of each row block are recomputed on the matrix cores (the
@@ -81,11 +81,12 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         const int c2 = i / (OD * 9), rem = i - c2 * OD * 9, c1 = rem / 9, tap = rem - c1 * 9;
         s_w2[(c2 * 9 + tap) * OD + c1] = w2[i];
     }
-    float accA[9], accX[9], accW1[3], accB2 = 0.0f, accB1 = 0.0f, accB1y = 0.0f;  // persistent over all rows of the workgroup
+    float accA[9], accX[9], accB2 = 0.0f, accB1 = 0.0f, accB1y = 0.0f;
+    float2 accW1[3];  // persistent over all rows of the workgroup
 #pragma unroll
     for (int k = 0; k < 9; ++k) { accA[k] = 0.0f; accX[k] = 0.0f; }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) accW1[k] = 0.0f;
+    for (int k = 0; k < 3; ++k) accW1[k] = make_float2(0.0f, 0.0f);
     // first-pass pair of this thread, extra-pass (pair, slice), dW1 (item, slice)
     const int pa_c2 = tid / OD, pa_c1 = tid - pa_c2 * OD;
     const bool pa_on = tid < G::PAIRS;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     const int px_c2 = px_pair / OD, px_c1 = px_pair - px_c2 * OD;
     const int i3 = tid % G::ITEMS3, s3 = tid / G::ITEMS3;
     const bool p3_on = s3 < G::RS3;
-    const int c1_3 = i3 / 9, c0_3 = (i3 - c1_3 * 9) / 3, kx_3 = i3 - c1_3 * 9 - c0_3 * 3;
+    const int cp_3 = i3 / 9, c0_3 = (i3 - cp_3 * 9) / 3, kx_3 = i3 - cp_3 * 9 - c0_3 * 3;
 
     // P2 role: lane quad = (row r2, channel PAIR cp), lane q of the quad = a quarter of the c2 range.  db2 role: thread (row br,
     // channel bc) of the first RBB * OD threads.
@@ -342,21 +343,25 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         if (p3_on) {
 #endif
             for (int rr = s3; rr < rv; rr += G::RS3) {
-                // one 7-wide line of dz1 at a time: the whole 7x7 plane in registers (52) next to the prefetched block (29)
-                // went over the register file and the tail of the prefetch was spilled load by load
-                const float *pd = s_dz1 + (size_t)(rr * (OD / 2) + (c1_3 >> 1)) * kDz1Unit + (c1_3 & 1);  // pair-interleaved (P2)
+                // one 7-wide line of dz1 at a time (the whole plane in registers next to the prefetched block went over the
+                // register file); BOTH channels of the pair as P2 left them interleaved: packed FMAs on natural pairs again
+                const float2 *pd = (const float2 *)(s_dz1 + (size_t)(rr * (OD / 2) + cp_3) * kDz1Unit);
                 const float *in = s_in + rr * 244 + c0_3 * 81 + kx_3 * 9;
 #pragma unroll
                 for (int x = 0; x < 7; ++x) {
-                    float dz[7], v[9];
+                    float2 dz[7];
+                    float v[9];
 #pragma unroll
-                    for (int y = 0; y < 7; ++y) dz[y] = pd[2 * (x * 7 + y)];
+                    for (int y = 0; y < 7; ++y) dz[y] = pd[x * 7 + y];
 #pragma unroll
                     for (int y = 0; y < 9; ++y) v[y] = in[x * 9 + y];
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                        for (int y = 0; y < 7; ++y) accW1[ky] = fmaf(dz[y], v[y + ky], accW1[ky]);
+                        for (int y = 0; y < 7; ++y) {
+                            accW1[ky].x = fmaf(dz[y].x, v[y + ky], accW1[ky].x);
+                            accW1[ky].y = fmaf(dz[y].y, v[y + ky], accW1[ky].y);
+                        }
                 }
             }
         }
@@ -379,11 +384,11 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         pp[kBlock * 18 + tid] = t;
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) pp[kBlock * 18 + OD + tid * 3 + k] = accW1[k];
+    for (int k = 0; k < 3; ++k) { pp[kBlock * 18 + OD + tid * 6 + k] = accW1[k].x; pp[kBlock * 18 + OD + tid * 6 + 3 + k] = accW1[k].y; }
     if (tid < OD) {
         float t = 0.0f;
         for (int k = 0; k < G::RBB; ++k) t += s_dz2[tid * 16 + k];
-        pp[kBlock * 18 + OD + kBlock * 3 + tid] = t;
+        pp[kBlock * 18 + OD + kBlock * 6 + tid] = t;
     }
 }
 
@@ -410,11 +415,12 @@ __global__ __launch_bounds__(64 * kRedY) void k_conv9_bwd_reduce(const float *__
                 for (int sl = 0; sl < G::XSLICES && sl < 8; ++sl) off[cnt++] = kBlock * 9 + (sl * G::EXTRA + (pair - kBlock)) * 9 + tap;
         } else if (i < n2 + nb) {                            // db2
             off[cnt++] = kBlock * 18 + (i - n2);
-        } else if (i < n2 + nb + n1) {                       // dW1[c1][c0][kx][ky]: item = (c1*3+c0)*3+kx, ky
-            const int jx = i - n2 - nb, item = jx / 3, ky = jx - item * 3;
-            for (int sl = 0; sl < G::RS3; ++sl) off[cnt++] = kBlock * 18 + OD + (sl * G::ITEMS3 + item) * 3 + ky;
+        } else if (i < n2 + nb + n1) {                       // dW1[c1][c0][kx][ky]: thread item = ((c1 / 2) * 3 + c0) * 3 + kx
+            const int jx = i - n2 - nb, c1 = jx / 27, r = jx - c1 * 27, ky = r % 3;   // r = (c0 * 3 + kx) * 3 + ky
+            const int item = (c1 >> 1) * 9 + r / 3;
+            for (int sl = 0; sl < G::RS3; ++sl) off[cnt++] = kBlock * 18 + OD + (sl * G::ITEMS3 + item) * 6 + (c1 & 1) * 3 + ky;
         } else {                                             // db1
-            off[cnt++] = kBlock * 18 + OD + kBlock * 3 + (i - n2 - nb - n1);
+            off[cnt++] = kBlock * 18 + OD + kBlock * 6 + (i - n2 - nb - n1);
         }
         for (int k = 0; k < cnt; ++k) {
             float a0 = 0.0f, a1 = 0.0f;
