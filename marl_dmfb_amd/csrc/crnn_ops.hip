@@ -46,15 +46,17 @@ template <int OD> struct GeoB {
     static constexpr int RBB = ((kLdsBudget / 4 - FIXED_FLOATS) / ROW_FLOATS) < (kBlock / (2 * OD)) ? ((kLdsBudget / 4 - FIXED_FLOATS) / ROW_FLOATS)
                                                                                                    : (kBlock / (2 * OD));
     static constexpr size_t LDS_FLOATS = (size_t)FIXED_FLOATS + (size_t)RBB * ROW_FLOATS + OD * 28;  // + conv1 weights and biases
-    static constexpr int PAIRS = OD * OD;
-    // (c2, c1) pairs beyond the first kBlock: either exactly one more per thread (od 32) or a remainder that is
-    // spread over all threads by giving each (pair, row slice) to a different thread (od 24: 64 pairs x 8 slices)
-    static constexpr int EXTRA = PAIRS - kBlock;
-    static constexpr int XSLICES = EXTRA > 0 ? kBlock / EXTRA : 1;
+    // dW2 work units (c2, channel PAIR of c1): the first NA units one thread each over all rows; the remainder (od 24: 32 units)
+    // spread over the upper half of the workgroup, each (unit, row slice) a different thread (32 units x 8 slices)
+    static constexpr int UNITS = OD * (OD / 2);
+    static constexpr int NA = UNITS >= kBlock ? kBlock : kBlock / 2;
+    static constexpr int NB = UNITS - NA;
+    static constexpr int XSLICES = NB > 0 ? (kBlock - NA) / NB : 1;
+    static_assert(NB >= 0 && (NB == 0 || (NA + NB * XSLICES <= kBlock && XSLICES <= 8)), "dW2 roles");
     // dW1 work items (c1, c0, kx) x row slices
     static constexpr int ITEMS3 = (OD / 2) * 9;  // (channel PAIR, c0, kx)
     static constexpr int RS3 = kBlock / ITEMS3;  // 4 (od 24) or 3 (od 32)
-    // partial vector: dW2 first pass [kBlock][9] | dW2 extra [kBlock][9] | db2 [OD] | dW1 [kBlock][2 channels][3] | db1 [OD]
+    // partial vector: dW2 [kBlock][9 taps][2 channels] (thread slot) | db2 [OD] | dW1 [kBlock][2 channels][3] | db1 [OD]
     static constexpr int PART = kBlock * 9 + kBlock * 9 + OD + kBlock * 6 + OD;
 };
 
@@ -81,19 +83,19 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         const int c2 = i / (OD * 9), rem = i - c2 * OD * 9, c1 = rem / 9, tap = rem - c1 * 9;
         s_w2[(c2 * 9 + tap) * OD + c1] = w2[i];
     }
-    float accA[9], accX[9], accB2 = 0.0f, accB1 = 0.0f, accB1y = 0.0f;
-    float2 accW1[3];  // persistent over all rows of the workgroup
+    float accB2 = 0.0f, accB1 = 0.0f, accB1y = 0.0f;
+    float2 accW2[9], accW1[3];  // persistent over all rows of the workgroup
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { accA[k] = 0.0f; accX[k] = 0.0f; }
+    for (int k = 0; k < 9; ++k) accW2[k] = make_float2(0.0f, 0.0f);
 #pragma unroll
     for (int k = 0; k < 3; ++k) accW1[k] = make_float2(0.0f, 0.0f);
-    // first-pass pair of this thread, extra-pass (pair, slice), dW1 (item, slice)
-    const int pa_c2 = tid / OD, pa_c1 = tid - pa_c2 * OD;
-    const bool pa_on = tid < G::PAIRS;
-    const int px_pair = G::EXTRA > 0 ? kBlock + (G::EXTRA == kBlock ? tid : tid % (G::EXTRA > 0 ? G::EXTRA : 1)) : 0;
-    const int px_slice = (G::EXTRA > 0 && G::EXTRA != kBlock) ? tid / G::EXTRA : 0;
-    const bool px_on = G::EXTRA > 0 && px_pair < G::PAIRS && px_slice < G::XSLICES;
-    const int px_c2 = px_pair / OD, px_c1 = px_pair - px_c2 * OD;
+    // dW2 role: unit (c2, channel pair), first row and row step; dW1 (item, slice)
+    const bool pa_full = tid < G::NA;
+    const int pa_unit = pa_full ? tid : G::NA + (G::NB > 0 ? (tid - G::NA) % (G::NB > 0 ? G::NB : 1) : 0);
+    const int pa_slice = pa_full ? 0 : (G::NB > 0 ? (tid - G::NA) / (G::NB > 0 ? G::NB : 1) : 0);
+    const bool pa_on = pa_full || (G::NB > 0 && pa_slice < G::XSLICES);
+    const int pa_step = pa_full ? 1 : G::XSLICES;
+    const int pa_c2 = pa_unit / (OD / 2), pa_cp = pa_unit - pa_c2 * (OD / 2);
     const int i3 = tid % G::ITEMS3, s3 = tid / G::ITEMS3;
     const bool p3_on = s3 < G::RS3;
     const int cp_3 = i3 / 9, c0_3 = (i3 - cp_3 * 9) / 3, kx_3 = i3 - cp_3 * 9 - c0_3 * 3;
@@ -191,11 +193,11 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
 #pragma unroll
                 for (int qt = 0; qt < 3; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[qt][s], bw1[s], acc[qt], 0, 0, 0);
             if (c_chv) {
-                float *dst = s_a1 + (rr * OD + c_ch) * kA1Stride + kq * 4;
+                float *dst = s_a1 + ((rr * (OD / 2) + (c_ch >> 1)) * kA1Stride + kq * 4) * 2 + (c_ch & 1);  // [row][pair][position][2]
 #pragma unroll
                 for (int qt = 0; qt < 3; ++qt)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) dst[qt * 16 + q] = fmaxf(acc[qt][q], 0.0f);
+                    for (int q = 0; q < 4; ++q) dst[(qt * 16 + q) * 2] = fmaxf(acc[qt][q], 0.0f);
             }
         }
         if (c_sub == 0) {  // position 48 of every row: lane i gathers row i
@@ -206,20 +208,26 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
             if (c_chv) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (kq * 4 + q < G::RBB) s_a1[((kq * 4 + q) * OD + c_ch) * kA1Stride + 48] = fmaxf(acc[q], 0.0f);
+                    if (kq * 4 + q < G::RBB) s_a1[(((kq * 4 + q) * (OD / 2) + (c_ch >> 1)) * kA1Stride + 48) * 2 + (c_ch & 1)] = fmaxf(acc[q], 0.0f);
             }
         }
         __syncthreads();
         // ---- P1: dW2 (and db2)
-        auto pair_rows = [&](int c2, int c1, int r_begin, int r_step, float (&acc)[9]) {
+        // ---- P1: dW2[c2][c1][tap] += sum_pos dz2[c2][pos] * a1[c1][pos + tap] for BOTH channels of the unit's pair: every
+        // multiply-add a v_pk_fma_f32 on a natural register pair -- (sums of the two channels) += dz2 (broadcast) * (a1 of the two
+        // channels, interleaved in LDS).  One channel per thread, the compiler packed neighbouring taps and spent as many
+        // register moves as it saved multiply-adds; a thread also re-read dz2 for every single channel.
+        auto unit_rows = [&](int c2, int cp, int r_begin, int r_step) {
+#pragma unroll 1
             for (int rr = r_begin; rr < rv; rr += r_step) {
-                float dz[G::DZ2], a[kA1Stride];
+                float dz[G::DZ2];
+                float2 a[kA1Stride];
                 const float4 *pd = (const float4 *)__builtin_assume_aligned(s_dz2 + rr * G::DZ_ROW + c2 * G::DZ2, 16);
-                const float4 *pa = (const float4 *)__builtin_assume_aligned(s_a1 + (rr * OD + c1) * kA1Stride, 16);
+                const float4 *pa = (const float4 *)__builtin_assume_aligned(s_a1 + (size_t)(rr * (OD / 2) + cp) * 2 * kA1Stride, 16);
 #pragma unroll
                 for (int j = 0; j < G::DZ2 / 4; ++j) { const float4 t = pd[j]; dz[4 * j] = t.x; dz[4 * j + 1] = t.y; dz[4 * j + 2] = t.z; dz[4 * j + 3] = t.w; }
 #pragma unroll
-                for (int j = 0; j < kA1Stride / 4; ++j) { const float4 t = pa[j]; a[4 * j] = t.x; a[4 * j + 1] = t.y; a[4 * j + 2] = t.z; a[4 * j + 3] = t.w; }
+                for (int j = 0; j < kA1Stride / 2; ++j) { const float4 t = pa[j]; a[2 * j] = make_float2(t.x, t.y); a[2 * j + 1] = make_float2(t.z, t.w); }
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -227,8 +235,12 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
 #pragma unroll
                         for (int x = 0; x < 5; ++x)
 #pragma unroll
-                            for (int y = 0; y < 5; ++y)
-                                acc[kx * 3 + ky] = fmaf(dz[x * 5 + y], a[(x + kx) * 7 + y + ky], acc[kx * 3 + ky]);
+                            for (int y = 0; y < 5; ++y) {
+                                const float z = dz[x * 5 + y];
+                                const float2 v = a[(x + kx) * 7 + y + ky];
+                                accW2[kx * 3 + ky].x = fmaf(z, v.x, accW2[kx * 3 + ky].x);
+                                accW2[kx * 3 + ky].y = fmaf(z, v.y, accW2[kx * 3 + ky].y);
+                            }
             }
         };
         // db2[c2] += sum of dz2[row][c2][.]: thread (row br, channel bc).  Inside pair_rows (the thread of pair (c2, 0) has the
@@ -241,8 +253,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
             accB2 += t + pd[6].x;
         }
 #ifndef CRNN_PROBE_SKIP_P1
-        if (pa_on) pair_rows(pa_c2, pa_c1, 0, 1, accA);
-        if (px_on) pair_rows(px_c2, px_c1, px_slice, (G::EXTRA == kBlock) ? 1 : G::XSLICES, accX);
+        if (pa_on) unit_rows(pa_c2, pa_cp, pa_slice, pa_step);
 #endif
         // ---- P2: da1[c1][p] = sum over c2, tap of dz2[c2][p - tap] * W2[c2][c1][tap];  dz1 = da1 * (a1 > 0).
         // A thread owns TWO channels (c1 = 2 cp, 2 cp + 1) of one row and a quarter of the c2 range: every multiply-add is a
@@ -308,14 +319,13 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
             if (q2 == 0) {
 #endif
                 // ReLU mask of both channels as bits (vector loads first), then selects and 16-byte stores of two positions each
-                const float4 *actx = (const float4 *)__builtin_assume_aligned(s_a1 + (r2 * OD + 2 * cp2) * kA1Stride, 16);
-                const float4 *acty = actx + kA1Stride / 4;
+                const float4 *act = (const float4 *)__builtin_assume_aligned(s_a1 + (size_t)unit2 * 2 * kA1Stride, 16);  // (x, y) of 2 positions
                 unsigned long long lx = 0, ly = 0;
 #pragma unroll
-                for (int j = 0; j < 13; ++j) {
-                    const float4 a = actx[j], b = acty[j];
-                    lx |= (unsigned long long)((a.x > 0.0f ? 1u : 0u) | (a.y > 0.0f ? 2u : 0u) | (a.z > 0.0f ? 4u : 0u) | (a.w > 0.0f ? 8u : 0u)) << (4 * j);
-                    ly |= (unsigned long long)((b.x > 0.0f ? 1u : 0u) | (b.y > 0.0f ? 2u : 0u) | (b.z > 0.0f ? 4u : 0u) | (b.w > 0.0f ? 8u : 0u)) << (4 * j);
+                for (int j = 0; j < 25; ++j) {
+                    const float4 a = act[j];
+                    lx |= (unsigned long long)((a.x > 0.0f ? 1u : 0u) | (a.z > 0.0f ? 2u : 0u)) << (2 * j);
+                    ly |= (unsigned long long)((a.y > 0.0f ? 1u : 0u) | (a.w > 0.0f ? 2u : 0u)) << (2 * j);
                 }
                 float4 *dst4 = (float4 *)__builtin_assume_aligned(s_dz1 + (size_t)unit2 * kDz1Unit, 16);
                 float sx = 0.0f, sy = 0.0f;
@@ -359,8 +369,12 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                         for (int y = 0; y < 7; ++y) {
-                            accW1[ky].x = fmaf(dz[y].x, v[y + ky], accW1[ky].x);
-                            accW1[ky].y = fmaf(dz[y].y, v[y + ky], accW1[ky].y);
+                            // an explicit 2-vector fma: left to itself the vectoriser pairs neighbouring taps here, not the two
+                            // channels, and pays one register move per multiply-add for it
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            const f32x2 r = __builtin_elementwise_fma((f32x2){dz[y].x, dz[y].y}, (f32x2){v[y + ky], v[y + ky]},
+                                                                      (f32x2){accW1[ky].x, accW1[ky].y});
+                            accW1[ky] = make_float2(r.x, r.y);
                         }
                 }
             }
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     __syncthreads();
     float *pp = part + (size_t)blockIdx.x * G::PART;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { pp[tid * 9 + k] = accA[k]; pp[kBlock * 9 + tid * 9 + k] = accX[k]; }
+    for (int k = 0; k < 9; ++k) { pp[tid * 18 + 2 * k] = accW2[k].x; pp[tid * 18 + 2 * k + 1] = accW2[k].y; }
     if (tid < OD) {
         float t = 0.0f;
         for (int k = 0; k < G::RBB; ++k) t += s_dz2[OD * 16 + tid * 16 + k];
@@ -407,12 +421,12 @@ __global__ __launch_bounds__(64 * kRedY) void k_conv9_bwd_reduce(const float *__
     if (i < n2 + nb + n1 + nb) {
         // up to 8 source slots of output i inside one partial vector (offsets), all partial vectors share them
         int off[8], cnt = 0;
-        if (i < n2) {                                        // dW2[c2][c1][tap]
-            const int pair = i / 9, tap = i - pair * 9;
-            if (pair < kBlock) off[cnt++] = pair * 9 + tap;
-            else if (G::EXTRA == kBlock) off[cnt++] = kBlock * 9 + (pair - kBlock) * 9 + tap;
+        if (i < n2) {                                        // dW2[c2][c1][tap]: unit (c2, c1 / 2), component c1 & 1
+            const int pair = i / 9, tap = i - pair * 9, c2 = pair / OD, c1 = pair - c2 * OD;
+            const int unit = c2 * (OD / 2) + (c1 >> 1), comp = 2 * tap + (c1 & 1);
+            if (unit < G::NA) off[cnt++] = unit * 18 + comp;
             else
-                for (int sl = 0; sl < G::XSLICES && sl < 8; ++sl) off[cnt++] = kBlock * 9 + (sl * G::EXTRA + (pair - kBlock)) * 9 + tap;
+                for (int sl = 0; sl < G::XSLICES && sl < 8; ++sl) off[cnt++] = (G::NA + sl * G::NB + (unit - G::NA)) * 18 + comp;
         } else if (i < n2 + nb) {                            // db2
             off[cnt++] = kBlock * 18 + (i - n2);
         } else if (i < n2 + nb + n1) {                       // dW1[c1][c0][kx][ky]: thread item = ((c1 / 2) * 3 + c0) * 3 + kx
