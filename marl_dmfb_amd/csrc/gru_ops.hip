@@ -32,24 +32,32 @@ constexpr int KQ = 32;   // k-range per thread
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// The dot products run on TWO rows at a time: (row 2p, row 2p + 1) sit next to each other in LDS, so one weight (broadcast) times
+// such a pair is a v_pk_fma_f32 on a natural register pair -- half the instructions of the scalar chains, the same sums in the
+// same order per row.  Written as an explicit 2-vector fma (from scalar code the compiler formed no packed instruction here), with
+// the weights held as 4-vectors: a broadcast operand costs nothing when it is an element of a register tuple, and a move when
+// it is a lone register.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(kBlock) void k_gru_seq_fwd(const float *__restrict__ igates, const float *__restrict__ h0,
                                                         const float *__restrict__ w_hh, const float *__restrict__ b_ih,
                                                         const float *__restrict__ b_hh, int T, long R,
                                                         float *__restrict__ hs, float *__restrict__ gates) {
-    __shared__ __attribute__((aligned(16))) float s_h[RW][H];
+    __shared__ __attribute__((aligned(16))) float s_h[RW / 2][H][2];   // h of rows (2p, 2p + 1), interleaved
     __shared__ __attribute__((aligned(16))) float s_part[4][RW][3][H];
     const int tid = threadIdx.x, q = tid / H, u = tid - q * H;
     const long row0 = (long)blockIdx.x * RW;
     const int rv = (int)min((long)RW, R - row0);
-    float w[3][KQ];
+    f32x4 w[3][KQ / 4];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int k = 0; k < KQ; ++k) w[g][k] = w_hh[(size_t)(g * H + u) * H + q * KQ + k];
+        for (int k = 0; k < KQ / 4; ++k) w[g][k] = *(const f32x4 *)(w_hh + (size_t)(g * H + u) * H + q * KQ + 4 * k);
     const float bir = b_ih[u] + b_hh[u], biz = b_ih[H + u] + b_hh[H + u], bin = b_ih[2 * H + u], bhn = b_hh[2 * H + u];
     for (int i = tid; i < RW * H; i += kBlock) {
         const int rr = i / H, c = i - rr * H;
-        s_h[rr][c] = rr < rv ? h0[(row0 + rr) * H + c] : 0.0f;
+        s_h[rr >> 1][c][rr & 1] = rr < rv ? h0[(row0 + rr) * H + c] : 0.0f;
     }
     __syncthreads();
     const int ra = 2 * q;  // this thread finishes rows ra and ra + 1
@@ -62,19 +70,27 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_fwd(const float *__restrict_
 #pragma unroll
             for (int g = 0; g < 3; ++g) ig[s][g] = rr < rv ? igates[((size_t)t * R + row0 + rr) * 3 * H + g * H + u] : 0.0f;
         }
-        // partial h @ W_hh^T over my k-quarter, all RW rows
+        // partial h @ W_hh^T over my k-quarter, all RW rows, two rows per instruction
 #pragma unroll
-        for (int rr = 0; rr < RW; ++rr) {
-            float hc[KQ];
-            const float4 *ph = (const float4 *)(&s_h[rr][q * KQ]);
+        for (int rp = 0; rp < RW / 2; ++rp) {
+            const f32x4 *ph = (const f32x4 *)(&s_h[rp][q * KQ][0]);
+            f32x2 acc[3] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
-            for (int j = 0; j < KQ / 4; ++j) { const float4 v = ph[j]; hc[4 * j] = v.x; hc[4 * j + 1] = v.y; hc[4 * j + 2] = v.z; hc[4 * j + 3] = v.w; }
+            for (int j = 0; j < KQ / 4; ++j) {   // k = 4j .. 4j + 3: two 16-byte reads of (h_2p[k], h_2p+1[k]) pairs
+                const f32x4 v0 = ph[2 * j], v1 = ph[2 * j + 1];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const f32x4 wv = w[g][j];
+                    acc[g] = __builtin_elementwise_fma((f32x2){wv.x, wv.x}, (f32x2){v0.x, v0.y}, acc[g]);
+                    acc[g] = __builtin_elementwise_fma((f32x2){wv.y, wv.y}, (f32x2){v0.z, v0.w}, acc[g]);
+                    acc[g] = __builtin_elementwise_fma((f32x2){wv.z, wv.z}, (f32x2){v1.x, v1.y}, acc[g]);
+                    acc[g] = __builtin_elementwise_fma((f32x2){wv.w, wv.w}, (f32x2){v1.z, v1.w}, acc[g]);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < KQ; ++k) acc = fmaf(w[g][k], hc[k], acc);
-                s_part[q][rr][g][u] = acc;
+                s_part[q][2 * rp][g][u] = acc[g].x;
+                s_part[q][2 * rp + 1][g][u] = acc[g].y;
             }
         }
         __syncthreads();
@@ -88,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_fwd(const float *__restrict_
                 const float rg = sigmoidf_(ig[s][0] + hr + bir);
                 const float zg = sigmoidf_(ig[s][1] + hz + biz);
                 const float ng = tanhf(ig[s][2] + bin + rg * hn);
-                const float hp = s_h[rr][u];
+                const float hp = s_h[rr >> 1][u][rr & 1];
                 const float hnew = (1.0f - zg) * ng + zg * hp;
                 const size_t o = ((size_t)t * R + row0 + rr);
                 hs[o * H + u] = hnew;
@@ -96,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_fwd(const float *__restrict_
                     gates[o * 4 * H + u] = rg; gates[o * 4 * H + H + u] = zg; gates[o * 4 * H + 2 * H + u] = ng;
                     gates[o * 4 * H + 3 * H + u] = hn;
                 }
-                s_h[rr][u] = hnew;  // only this thread reads s_h[rr][u] between the two barriers
+                s_h[rr >> 1][u][rr & 1] = hnew;  // only this thread reads this element between the two barriers
             }
         }
         __syncthreads();
@@ -108,16 +124,19 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
                                                         const float *__restrict__ w_hh, int T, long R,
                                                         float *__restrict__ d_ig, float *__restrict__ d_hg,
                                                         float *__restrict__ d_h0, float *__restrict__ bias_part) {
-    __shared__ __attribute__((aligned(16))) float s_dhg[RW][3][H];
+    __shared__ __attribute__((aligned(16))) float s_dhg[RW / 2][3][H][2];  // gate gradients of rows (2p, 2p + 1), interleaved
     __shared__ __attribute__((aligned(16))) float s_part[4][RW][H];
     const int tid = threadIdx.x, q = tid / H, u = tid - q * H;
     const long row0 = (long)blockIdx.x * RW;
     const int rv = (int)min((long)RW, R - row0);
-    float wt[3][KQ];  // W_hh[g*H + 32q + k][u]: column u of the rows of my k-quarter
+    f32x4 wt[3][KQ / 4];  // W_hh[g*H + 32q + k][u]: column u of the rows of my k-quarter, four k per register tuple
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int k = 0; k < KQ; ++k) wt[g][k] = w_hh[(size_t)(g * H + q * KQ + k) * H + u];
+        for (int k = 0; k < KQ / 4; ++k) {
+            const float *col = w_hh + (size_t)(g * H + q * KQ + 4 * k) * H + u;
+            wt[g][k] = (f32x4){col[0], col[H], col[2 * H], col[3 * H]};
+        }
     const int ra = 2 * q;
     float gh[2] = {0.0f, 0.0f};  // dL/dh_t arriving from the future for my two (row, u) entries
     float bs_r = 0.0f, bs_z = 0.0f, bs_n = 0.0f, bs_hn = 0.0f;  // column sums of the gate gradients (bias gradients)
@@ -144,24 +163,27 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
                 d_hg[o * 3 * H + u] = dpr; d_hg[o * 3 * H + H + u] = dpz; d_hg[o * 3 * H + 2 * H + u] = dhn;
                 bs_r += dpr; bs_z += dpz; bs_n += dpn; bs_hn += dhn;
             }
-            s_dhg[rr][0][u] = dpr; s_dhg[rr][1][u] = dpz; s_dhg[rr][2][u] = dhn;
+            s_dhg[rr >> 1][0][u][rr & 1] = dpr; s_dhg[rr >> 1][1][u][rr & 1] = dpz; s_dhg[rr >> 1][2][u][rr & 1] = dhn;
         }
         __syncthreads();
-        // partial W_hh^T d_hgates over my k-quarter of the gate rows, output column u, all RW rows
+        // partial W_hh^T d_hgates over my k-quarter of the gate rows, output column u, all RW rows, two rows per instruction
 #pragma unroll
-        for (int rr = 0; rr < RW; ++rr) {
-            float acc = 0.0f;
+        for (int rp = 0; rp < RW / 2; ++rp) {
+            f32x2 acc = {0.0f, 0.0f};
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                const float4 *pd = (const float4 *)(&s_dhg[rr][g][q * KQ]);
+                const f32x4 *pd = (const f32x4 *)(&s_dhg[rp][g][q * KQ][0]);
 #pragma unroll
                 for (int j = 0; j < KQ / 4; ++j) {
-                    const float4 v = pd[j];
-                    acc = fmaf(wt[g][4 * j], v.x, acc); acc = fmaf(wt[g][4 * j + 1], v.y, acc);
-                    acc = fmaf(wt[g][4 * j + 2], v.z, acc); acc = fmaf(wt[g][4 * j + 3], v.w, acc);
+                    const f32x4 v0 = pd[2 * j], v1 = pd[2 * j + 1], wv = wt[g][j];
+                    acc = __builtin_elementwise_fma((f32x2){wv.x, wv.x}, (f32x2){v0.x, v0.y}, acc);
+                    acc = __builtin_elementwise_fma((f32x2){wv.y, wv.y}, (f32x2){v0.z, v0.w}, acc);
+                    acc = __builtin_elementwise_fma((f32x2){wv.z, wv.z}, (f32x2){v1.x, v1.y}, acc);
+                    acc = __builtin_elementwise_fma((f32x2){wv.w, wv.w}, (f32x2){v1.z, v1.w}, acc);
                 }
             }
-            s_part[q][rr][u] = acc;
+            s_part[q][2 * rp][u] = acc.x;
+            s_part[q][2 * rp + 1][u] = acc.y;
         }
         __syncthreads();
 #pragma unroll
