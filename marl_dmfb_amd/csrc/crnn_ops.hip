@@ -100,9 +100,13 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
     const bool p3_on = s3 < G::RS3;
     const int cp_3 = i3 / 9, c0_3 = (i3 - cp_3 * 9) / 3, kx_3 = i3 - cp_3 * 9 - c0_3 * 3;
 
-    // P2 role: lane quad = (row r2, channel PAIR cp), lane q of the quad = a quarter of the c2 range.  db2 role: thread (row br,
+    // P2 role: kSplit2 neighbouring lanes = (row r2, channel PAIR cp), lane q of them = its share of the c2 range.  db2 role: thread (row br,
     // channel bc) of the first RBB * OD threads.
-    const int q2 = tid & 3, unit2 = tid >> 2;
+    // (od 24: the dW2 phase keeps waves 0-3 busy over all rows and waves 4-7 only for their row slices, so P2 lives on waves 4-7
+    // alone, two lanes per unit: every SIMD then carries one long P1 wave and one P2 wave instead of two waves that both run
+    // P1 then P2 with very different P1 lengths.  od 32: P1 is even over the waves, P2 takes four lanes per unit on waves 0-5.)
+    constexpr int kSplit2 = G::NB > 0 ? 2 : 4, kBase2 = G::NB > 0 ? kBlock / 2 : 0;
+    const int q2 = (tid - kBase2) & (kSplit2 - 1), unit2 = tid >= kBase2 ? (tid - kBase2) / kSplit2 : G::RBB * (OD / 2);
     const int r2 = unit2 / (OD / 2), cp2 = unit2 - r2 * (OD / 2);
     const int br = tid / OD, bc = tid - br * OD;
 
@@ -256,11 +260,11 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
         if (pa_on) unit_rows(pa_c2, pa_cp, pa_slice, pa_step);
 #endif
         // ---- P2: da1[c1][p] = sum over c2, tap of dz2[c2][p - tap] * W2[c2][c1][tap];  dz1 = da1 * (a1 > 0).
-        // A thread owns TWO channels (c1 = 2 cp, 2 cp + 1) of one row and a quarter of the c2 range: every multiply-add is a
+        // A thread owns TWO channels (c1 = 2 cp, 2 cp + 1) of one row and a quarter (od 24: half) of the c2 range: every multiply-add is a
         // v_pk_fma_f32 on a natural register pair -- (da[p] of both channels) += dz2 (broadcast) * (W2 of both channels, adjacent
         // in the [c2][tap][c1] LDS copy).  With one channel per thread the compiler packed neighbouring positions instead and
-        // spent 155 register moves per 135 multiply-adds on lining the pairs up.  The four quarter sums of a quad meet through
-        // DPP (no LDS, no barrier); lane 0 of the quad applies the ReLU mask and writes dz1, pair-interleaved:
+        // spent 155 register moves per 135 multiply-adds on lining the pairs up.  The partial sums of a unit's lanes meet through
+        // DPP (no LDS, no barrier); lane 0 of the unit applies the ReLU mask and writes dz1, pair-interleaved:
         // s_dz1[(row * OD/2 + cp) * kDz1Unit + 2 * position + (c1 & 1)]  (kDz1Unit = 108: P3's eight channel pairs per wave on
         // eight different bank groups).
 #ifndef CRNN_PROBE_SKIP_P2
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
             float2 da[49];
 #pragma unroll
             for (int k = 0; k < 49; ++k) da[k] = make_float2(0.0f, 0.0f);
-            const int cbeg = q2 * (OD / 4), cend = cbeg + OD / 4;
+            const int cbeg = q2 * (OD / kSplit2), cend = cbeg + OD / kSplit2;
 #pragma unroll 1
             for (int c2 = cbeg; c2 < cend; ++c2) {
                 float dz[G::DZ2];
@@ -306,11 +310,13 @@ __global__ __launch_bounds__(kBlock) void k_conv9_bwd(const int8_t *__restrict__
                 asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(da[k].x));
                 asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(da[k].y));
             }
-            asm volatile("s_nop 1");
+            if (kSplit2 == 4) {
+                asm volatile("s_nop 1");
 #pragma unroll
-            for (int k = 0; k < 49; ++k) {
-                asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(da[k].x));
-                asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(da[k].y));
+                for (int k = 0; k < 49; ++k) {
+                    asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(da[k].x));
+                    asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(da[k].y));
+                }
             }
 #endif
 #ifdef CRNN_PROBE_P2_NO_MASK
