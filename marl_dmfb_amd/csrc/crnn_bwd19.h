@@ -49,7 +49,11 @@ template <int OD> struct GeoB19 {
     // partial vector of a workgroup: dW3 | dW1 | bias sums per thread: [kBlockB] dz3+dz2, [kBlockB] dz1
     static constexpr int PART = N_W3 + N_W1 + 2 * kBlockB;
     static constexpr int GRADS = N_W3 + OD + N_W1 + OD;   // dW3 | db3 | dW1 | db1
-    static constexpr size_t LDS_FLOATS = (size_t)RBB * (IMG / 4 + ROW_A + ROW_B + ROW_C + ROW_D) + W_FLOATS;
+    // per K index of the two dW3 passes (k = (row, position)): offset of dz inside s_C / s_D and of the window origin inside s_B /
+    // s_A, as int2; one table read per k-step instead of two divisions and their multiplies
+    static constexpr int KA = (RBB * 25 + 3) / 4 * 4, KB = (RBB * 49 + 3) / 4 * 4;
+    static constexpr int LUT_INTS = 2 * (KA + KB);
+    static constexpr size_t LDS_FLOATS = (size_t)RBB * (IMG / 4 + ROW_A + ROW_B + ROW_C + ROW_D) + W_FLOATS + LUT_INTS;
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "one workgroup per CU");
     static_assert(OD * 16 <= kBlockB, "bias sums: one thread per (channel, 1/16 of the positions)");
 };
@@ -115,6 +119,8 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
     float *s_C = s_B + G::RBB * G::ROW_B;                    // [RBB][OD][85]  dz3 zero-padded to 9x9, later dz1 (9x9)
     float *s_D = s_C + G::RBB * G::ROW_C;                    // [RBB][OD][125] dz2 zero-padded to 11x11
     float *s_W = s_D + G::RBB * G::ROW_D;                    // [OD][WS]       conv3 weights [c_out][c_in][tap], c_out stride WS
+    int2 *s_lutA = (int2 *)(s_W + G::W_FLOATS);              // [KA] dW3 pass a: (dz3 offset in s_C, a2 window origin in s_B) of k
+    int2 *s_lutB = s_lutA + G::KA;                           // [KB] dW3 pass b: (dz2 offset in s_D, a1 window origin in s_A) of k
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nh = (wave >> 1) & 1, sub = (wave & 1) + 2 * (wave >> 2);
     const int j = lane & 15, kq = lane >> 4;
@@ -126,6 +132,14 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
     // per launch: crnn_mfma.h); conv1's 7 B operands per lane stay in registers.
     for (int i = tid; i < OD * OD * 9; i += kBlockB) { const int co = i / (OD * 9); s_W[co * G::WS + (i - co * OD * 9)] = w3[i]; }
     for (int i = tid; i < OD * 27; i += kBlockB) s_B[i] = w1[i];       // [c_out][27]
+    for (int k = tid; k < G::KA; k += kBlockB) {
+        const int kc = k < G::RBB * 25 ? k : 0, rr = kc / 25, p = kc - rr * 25;
+        s_lutA[k] = make_int2(rr * G::ROW_C + (p / 5 + 2) * 9 + p % 5 + 2, rr * G::ROW_B + (p / 5) * 7 + p % 5);
+    }
+    for (int k = tid; k < G::KB; k += kBlockB) {
+        const int kc = k < G::RBB * 49 ? k : 0, rr = kc / 49, p = kc - rr * 49;
+        s_lutB[k] = make_int2(rr * G::ROW_D + (p / 7 + 2) * 11 + p % 7 + 2, rr * G::ROW_A + (p / 7) * 9 + p % 7);
+    }
     __syncthreads();
     float bw1[7];
     int off1[7];
@@ -291,9 +305,9 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
             for (int k0 = 0; k0 < K3; k0 += 4) {
                 const int k = k0 + kq;
                 const bool kv = k < K3;
-                const int rr = kv ? k / 25 : 0, p = kv ? k - rr * 25 : 0;
-                const float *za = s_C + rr * G::ROW_C + (p / 5 + 2) * 9 + p % 5 + 2;       // dz3[rr][.][p] in its padded plane
-                const float *zb = s_B + rr * G::ROW_B + (p / 5) * 7 + p % 5;                 // a2 window origin of position p
+                const int2 lo = s_lutA[k];   // (k < KA always: K3 rounded up to the step)
+                const float *za = s_C + lo.x;                                               // dz3[rr][.][p] in its padded plane
+                const float *zb = s_B + lo.y;                                               // a2 window origin of position p
                 const float a_raw = za[a_chc * G::CS1];
                 const float av = (kv && a_chv) ? a_raw : 0.0f;
 #pragma unroll
@@ -328,9 +342,9 @@ __global__ __launch_bounds__(kBlockB) void k_conv19_bwd(const int8_t *__restrict
             for (int k0 = 0; k0 < K2; k0 += 4) {
                 const int k = k0 + kq;
                 const bool kv = k < K2;
-                const int rr = kv ? k / 49 : 0, p = kv ? k - rr * 49 : 0;
-                const float *za = s_D + rr * G::ROW_D + (p / 7 + 2) * 11 + p % 7 + 2;
-                const float *zb = s_A + rr * G::ROW_A + (p / 7) * 9 + p % 7;
+                const int2 lo = s_lutB[k];
+                const float *za = s_D + lo.x;
+                const float *zb = s_A + lo.y;
                 const float a_raw = za[a_chc * G::CS4];
                 const float av = (kv && a_chv) ? a_raw : 0.0f;
 #pragma unroll
