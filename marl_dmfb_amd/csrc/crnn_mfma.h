@@ -34,7 +34,7 @@ __device__ unsigned long long *g_crnn_ts;
 // RBV: rows per workgroup iteration.  0 = the largest block one workgroup per CU can hold (16 rows at od 24, 12 at od 32:
 // 139 / 134 KB of LDS).  Two workgroups per CU (8 rows each) were built twice -- eight waves at 128 registers, and four waves
 // owning both channel halves -- and both measured SLOWER (register spills; tools/probe/conv9_mfma_w4.patch).
-template <int OD, int RBV = 0> struct GeoM {
+template <int OD, int RBV = 0, int NW = 8> struct GeoM {
     static constexpr int RB = RBV ? RBV : (OD <= 24 ? 16 : 12);  // rows per iteration (LDS-bound)
     static constexpr int CS = 53;                        // conv1 activation stride per channel: odd, so the epilogue's
                                                          // 16 channel lanes fall on different banks
@@ -47,7 +47,11 @@ template <int OD, int RBV = 0> struct GeoM {
     static constexpr int NSTEP2 = KQ * 9;                // conv2 k-steps (54 / 72)
     static constexpr int M1 = RB * 49, M2 = RB * 25;
     static constexpr int T2 = (M2 + 15) / 16;
-    static_assert(RB % 4 == 0 && RB <= 16, "conv1 tiling: rows split over 4 waves per half, one position-48 tile");
+    static constexpr int NSUB = NW / 2;                  // waves per channel half
+    static constexpr int BLOCK = 64 * NW;                // NW = 8: one workgroup per CU, two waves per SIMD; NW = 4 (RB 8): two
+                                                         // workgroups per CU, one wave each per SIMD, out of phase by themselves
+    static_assert(NW == 8 || NW == 4, "wave roles");
+    static_assert(RB % NSUB == 0 && RB <= 16, "conv1 tiling: rows split over NSUB waves per half, one position-48 tile");
     static constexpr int VEC = 18;                       // dir_x, dir_y, one-hot (<= 16) per row
     static constexpr int MLP = 10 * VEC + 10;            // the vector branch's weights [10][nin] and biases
     static constexpr size_t LDS_FLOATS = (size_t)RB * IN_STRIDE + (size_t)RB * ROW_A1 + (size_t)RB * OUT_STRIDE + (size_t)RB * VEC + MLP;
@@ -111,8 +115,8 @@ __device__ __forceinline__ void conv2_tiles(const float *s_a1, float *s_out, con
     }
 }
 
-template <int OD, int RBV = 0>
-__global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict__ obs, long obs_stride, long rows,
+template <int OD, int RBV = 0, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void k_conv9_mfma(const int8_t *__restrict__ obs, long obs_stride, long rows,
                                                         const float *__restrict__ w1, const float *__restrict__ b1,
                                                         const float *__restrict__ w2, const float *__restrict__ b2,
                                                         float *__restrict__ out, long out_stride, int out_cols,
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
     // live_chips != NULL (rollout with finished chips): only the rows of the *n_live chips listed in live_chips (rows_per_chip
     // consecutive rows each) are processed; input row = live_chips[k] * rows_per_chip + a, OUTPUT row = k * rows_per_chip + a
     // (compact).  `rows` is then the worst case the grid was sized for; the device-side count decides.
-    using G = GeoM<OD, RBV>;
+    using G = GeoM<OD, RBV, NW>;
+    constexpr int kBlockM = G::BLOCK;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *s_in = lds;                              // [RB][244]  float image of the pixel bytes
     float *s_a1 = s_in + G::RB * G::IN_STRIDE;      // [RB][OD][53] conv1 activations
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // wave w runs on SIMD w & 3: SIMDs 0,1 hold channel half 0, SIMDs 2,3 half 1; the two waves of a SIMD take
     // tiles sub, sub + 4, ... with sub = (w & 1) and (w & 1) + 2, so every SIMD gets 12 or 13 of the 25 conv2 tiles
-    const int nh = (wave >> 1) & 1, sub = (wave & 1) + 2 * (wave >> 2);
+    const int nh = (wave >> 1) & 1, sub = (wave & 1) + 2 * (wave >> 2);   // NW = 4: sub = wave & 1
     const int j = lane & 15, kq = lane >> 4;
     const int ch = nh * 16 + j;                     // the output channel this lane's B column / D column belongs to
     const bool chv = ch < OD;
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
     // loads), the lanes add lane + 64 v.  Per-thread element indices (row = i / 243 per lane) made the compiler hoist eight
     // 64-bit row offsets per lane out of the loop, spill them, and wait on every reload -- which, the memory counter being
     // in-order, also waited on the previous row byte: the eight loads of a block ran one after the other.
-    constexpr int RPW = (G::RB + 7) / 8, ROWB = 245;  // rows per wave; bytes of a row: 243 pixels, dir_x, dir_y
+    constexpr int RPW = (G::RB + NW - 1) / NW, ROWB = 245;  // rows per wave; bytes of a row: 243 pixels, dir_x, dir_y
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int pf[RPW][4], pfo[RPW];
     int pf_rv = 0;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
         pf_rv = b < n_blocks ? (int)min((long)G::RB, rows - r0) : 0;
 #pragma unroll
         for (int h = 0; h < RPW; ++h) {
-            const int rr = wave_u + 8 * h;
+            const int rr = wave_u + NW * h;
             if (rr < pf_rv) {  // wave-uniform
                 const long sr = src_row(r0 + rr);
                 const int8_t *row = obs + sr * obs_stride;
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
     auto park = [&]() {
 #pragma unroll
         for (int h = 0; h < RPW; ++h) {
-            const int rr = wave_u + 8 * h;
+            const int rr = wave_u + NW * h;
             if (rr < G::RB) {
                 const bool on = rr < pf_rv;   // rows past the end: finite zeros
                 float *dst = s_in + rr * G::IN_STRIDE;
@@ -282,13 +287,13 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
 #pragma unroll
                 for (int s = 0; s < 7; ++s) cv[0][qt][s] = s_in[gq[qt] + off1[s]];
 #pragma unroll
-            for (int i = 0; i < G::RB / 4; ++i) {
-                if (i + 1 < G::RB / 4) {
+            for (int i = 0; i < G::RB / G::NSUB; ++i) {
+                if (i + 1 < G::RB / G::NSUB) {
 #pragma unroll
                     for (int qt = 0; qt < 3; ++qt)
 #pragma unroll
                         for (int s = 0; s < 7; ++s)
-                            cv[(i + 1) & 1][qt][s] = s_in[4 * (i + 1) * G::IN_STRIDE + gq[qt] + off1[s]];
+                            cv[(i + 1) & 1][qt][s] = s_in[G::NSUB * (i + 1) * G::IN_STRIDE + gq[qt] + off1[s]];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc[3];
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
                     for (int qt = 0; qt < 3; ++qt) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i & 1][qt][s], bw1[s], acc[qt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (chv) {
-                    float *dst = s_a1 + (sub + 4 * i) * G::ROW_A1 + ch * G::CS + kq * 4;
+                    float *dst = s_a1 + (sub + G::NSUB * i) * G::ROW_A1 + ch * G::CS + kq * 4;
 #pragma unroll
                     for (int qt = 0; qt < 3; ++qt)
 #pragma unroll
@@ -333,8 +338,8 @@ __global__ __launch_bounds__(kBlockM) void k_conv9_mfma(const int8_t *__restrict
             int ts_k = 8;
 #endif
 #pragma unroll 1
-            for (; t + 4 < G::T2; t += 8) {
-                conv2_tiles<OD, RBV, 2>(s_a1, s_out, bw2, bias2, t, t + 4, j, kq, ch, chv);
+            for (; t + G::NSUB < G::T2; t += 2 * G::NSUB) {
+                conv2_tiles<OD, RBV, 2>(s_a1, s_out, bw2, bias2, t, t + G::NSUB, j, kq, ch, chv);
 #ifdef CRNN_PROBE_TS
                 CRNN_TS(ts_k); ++ts_k;
 #endif

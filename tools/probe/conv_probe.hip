@@ -9,7 +9,12 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 int main(int argc, char **argv) {
     constexpr int OD = 24;
-    using G = crnn_mfma::GeoM<OD>;
+#ifdef CRNN_PROBE_NW4   // two 4-wave workgroups per CU, 8 rows each
+    constexpr int RBV = 8, NW = 4, PER_CU = 2;
+#else
+    constexpr int RBV = 0, NW = 8, PER_CU = 1;
+#endif
+    using G = crnn_mfma::GeoM<OD, RBV, NW>;
     const long rows = argc > 1 ? atol(argv[1]) : 81920;
     int8_t *obs; float *w1, *b1, *w2, *b2, *out;
     CK(hipMalloc(&obs, rows * 245)); CK(hipMalloc(&w1, OD * 27 * 4)); CK(hipMalloc(&b1, OD * 4));
@@ -21,17 +26,17 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(w1, hw.data(), OD * 27 * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(b1, hw.data(), OD * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b2, hw.data(), OD * 4, hipMemcpyHostToDevice));
     const size_t lds = G::LDS_FLOATS * 4;
-    CK(hipFuncSetAttribute((const void *)crnn_mfma::k_conv9_mfma<OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)crnn_mfma::k_conv9_mfma<OD, RBV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long nb = (rows + G::RB - 1) / G::RB;
-    const int grid = nb < 256 ? nb : 256;
+    const int grid = nb < 256 * PER_CU ? nb : 256 * PER_CU;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int it = 0; it < 3; ++it)
-        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L, 0,
+        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD, RBV, NW>), dim3(grid), dim3(G::BLOCK), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L, 0,
                            (const int8_t *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 1);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     for (int it = 0; it < 20; ++it)
-        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L, 0,
+        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD, RBV, NW>), dim3(grid), dim3(G::BLOCK), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L, 0,
                            (const int8_t *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 1);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -40,7 +45,7 @@ int main(int argc, char **argv) {
     {   // phase stamps of the second row block of workgroups 0 and 100: counter ticks relative to the workgroup's earliest loop top
         unsigned long long *ts; CK(hipMalloc(&ts, (size_t)grid * 8 * 16 * 8)); CK(hipMemset(ts, 0, (size_t)grid * 8 * 16 * 8));
         CK(hipMemcpyToSymbol(HIP_SYMBOL(crnn_mfma::g_crnn_ts), &ts, sizeof(ts)));
-        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD>), dim3(grid), dim3(crnn_mfma::kBlockM), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L, 0,
+        hipLaunchKernelGGL((crnn_mfma::k_conv9_mfma<OD, RBV, NW>), dim3(grid), dim3(G::BLOCK), lds, 0, obs, 245L, rows, w1, b1, w2, b2, out, 600L, 0,
                            (const int8_t *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 1);
         CK(hipDeviceSynchronize());
         std::vector<unsigned long long> hts((size_t)grid * 8 * 16); CK(hipMemcpy(hts.data(), ts, hts.size() * 8, hipMemcpyDeviceToHost));
