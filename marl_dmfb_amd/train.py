@@ -37,7 +37,8 @@ class Trainer:
         self.episode_constraints, self.success_rate, self.time_cost = [], [], []
         self.save_path = args.result_dir + '/' + args.alg + '/fov{}/{}by{}-{}d{}b'.format(
             args.fov, args.width, args.length, args.drop_num, args.block_num)
-        self.time_steps = 0
+        self._time_steps = 0
+        self._pending_steps = None  # data parallel: the reduced step count of the last round, still on the device
         self.trained_times = 0
         self.len_bound = 0  # longest episode stored so far (first terminated step + 1), kept on the host
         self.dist = bool(self.agents.policy.dist)
@@ -75,11 +76,42 @@ class Trainer:
             if pol.ride_along_sum is None:  # no learn ran this round (train_time == 0): reduce the count by itself
                 pol.ride_along_sum = pol.all_reduce_sum(pol.ride_along)
                 pol.ride_along = None
-            hi, lo = (int(round(v)) for v in pol.ride_along_sum.tolist())
-            self.time_steps += hi * 4096 + lo
+            self._flush_steps()
+            # copied to the host behind this round's learns without blocking; read when somebody asks for time_steps
+            # (run() does, every round), by when the copy of a loop that does not ask (bench.py) has long finished
+            src = pol.ride_along_sum
+            if src.is_cuda:
+                host = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+                host.copy_(src, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending_steps = (host, ev)
+            else:
+                self._pending_steps = (src, None)
         else:
-            self.time_steps += local_host
+            self._time_steps += local_host
         return played
+
+    def _flush_steps(self):
+        if self._pending_steps is not None:
+            host, ev = self._pending_steps
+            if ev is not None:
+                ev.synchronize()
+            hi, lo = (int(round(v)) for v in host.tolist())
+            self._time_steps += hi * 4096 + lo
+            self._pending_steps = None
+
+    @property
+    def time_steps(self):
+        """Global count of collected env steps (train.py:65).  Under data parallelism the last round's reduced count is read
+        from the device only here: a loop that does not look at it (bench.py) never waits for the last learn of a round."""
+        self._flush_steps()
+        return self._time_steps
+
+    @time_steps.setter
+    def time_steps(self, v):
+        self._flush_steps()
+        self._time_steps = int(v)
 
     def _evaluate_and_record(self, evaluator=None):
         ev = evaluator or self.rolloutWorker
