@@ -11,6 +11,7 @@ parameter tensor, with the HIP GRU or the per-step aten cell, with the HIP conv 
 import glob
 import os
 
+import numpy as np
 import pytest
 
 from vdn_helpers import learn_golden_check
@@ -30,3 +31,34 @@ def test_learn_matches_reference_gpu(path, replay_dtypes):
     """fused_td: the batch in the replay buffer's dtypes -> k_td_forward/backward + time-major Q values, i.e. what Trainer.run
     and bench.py execute; tensor_op_td: the golden's float64 rewards -> the torch TD block.  Both against the reference's numbers."""
     learn_golden_check(path, 'cuda:0', rtol=1e-5, atol=1e-5, replay_dtypes=replay_dtypes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', FILES, ids=os.path.basename)
+def test_learn_with_host_length_bound_matches_reference_gpu(path):
+    """The shipped default of Trainer.collect_and_learn (args.host_len_bound): the learn is handed max_len = the slots of the
+    batch instead of reading the batch's own length back, through the fused TD block -- the path bench.py times."""
+    learn_golden_check(path, 'cuda:0', rtol=1e-5, atol=1e-5, replay_dtypes=True, host_len_bound=True)
+
+
+@pytest.mark.parametrize('path', FILES, ids=os.path.basename)
+def test_learn_with_host_length_bound_matches_reference_cpu(path):
+    learn_golden_check(path, 'cpu', rtol=1e-5, atol=1e-5, host_len_bound=True)
+
+
+@pytest.mark.parametrize('path', FILES, ids=os.path.basename)
+def test_goldens_hold_padded_and_early_terminated_episodes(path):
+    """Every learn golden pins mask = 1 - padded, (1 - terminated) and the length trim (policy/vdn.py:115-122,
+    agent/agent.py:51-61) to the reference: at least a third of its episodes carry padded steps, lengths differ, and an
+    episode that ends early has terminated = 1 on its last valid step."""
+    g = np.load(path)
+    padded, term = g['padded'][:, :, 0].astype(bool), g['terminated'][:, :, 0].astype(bool)
+    lens = (~padded).sum(1)
+    T = padded.shape[1]
+    assert (lens < T).sum() * 3 >= len(lens), lens
+    assert len(set(lens.tolist())) >= 3, lens
+    for b, ln in enumerate(lens):
+        assert not padded[b, :ln].any() and padded[b, ln:].all()
+        assert term[b, ln - 1] and not term[b, :ln - 1].any() and term[b, ln:].all()
+    if os.path.basename(path) == 'vdn_learn_4d_od24_short.npz':
+        assert lens.max() < T          # the batch's own length is below the limit: max_len = T adds all-padded steps

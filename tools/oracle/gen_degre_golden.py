@@ -27,7 +27,7 @@ QUEUE = ref_shim.DrawQueue()
 ref_shim.patch_random(QUEUE)
 
 
-def main(seed=4, W=10, L=10, n=4, fov=9, epochs=3, tasks=3):
+def main(seed=4, W=10, L=10, n=4, fov=9, epochs=4, tasks=3):
     rng = np.random.default_rng(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
@@ -50,6 +50,12 @@ def main(seed=4, W=10, L=10, n=4, fov=9, epochs=3, tasks=3):
             pts = np.stack([rng.integers(0, W, 2 * n), rng.integers(0, L, 2 * n)], axis=1)
             d = pts[:, None, :] - pts[None, :, :]
             if ((d ** 2).sum(-1) + np.eye(2 * n, dtype=int) * 99).min() > 2:
+                k = len(task_log)
+                if k // tasks == 1 or k == 3 * tasks:        # epoch 1 (and the first task of epoch 3: a mixed epoch, success 1/3): every droplet starts on its goal -> each episode SUCCEEDS after one step
+                    pts[n:] = pts[:n]      # (success = 1, steps < limit: the early-exit branches of rollout.py:41-67 inside the ageing loop)
+                elif k % tasks == 1:       # mixed epochs: three on their goals, one a single cell away (the greedy net decides)
+                    pts[n:] = pts[:n]
+                    pts[n, 0] = pts[0, 0] + (1 if pts[0, 0] < W - 1 else -1)
                 task_log.append(pts.copy())
                 draw_log.append([])
                 return pts

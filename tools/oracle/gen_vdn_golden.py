@@ -54,19 +54,68 @@ def sample_idx(numel, k=512):
     return np.unique(np.linspace(0, numel - 1, min(k, numel)).astype(np.int64))
 
 
-def gen_learn(tag, drop_num, W, L, fov, B, seed):
+def near_task(rng, W, L, n, max_gap):
+    """Starts anywhere, every goal 1..max_gap cells (Manhattan) from its own start; all 2n points pairwise d^2 > 2 except a
+    droplet's own (start, goal) pair -- the rule of _Generate_Start_End (dmfb.py:200-226) with that one exception."""
+    while True:
+        st = np.stack([rng.integers(0, W, n), rng.integers(0, L, n)], axis=1)
+        en = st.copy()
+        for i in range(n):
+            gap = int(rng.integers(1, max_gap + 1))
+            dx = int(rng.integers(0, gap + 1))
+            en[i] = st[i] + np.array([dx * rng.choice([-1, 1]), (gap - dx) * rng.choice([-1, 1])])
+        if en.min() < 0 or en[:, 0].max() >= W or en[:, 1].max() >= L:
+            continue
+        pts = np.concatenate([st, en])
+        d = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1) + np.eye(2 * n, dtype=int) * 99
+        for i in range(n):
+            d[i, n + i] = d[n + i, i] = 99
+        if d.min() > 2:
+            return st, en
+
+
+def gen_learn(tag, drop_num, W, L, fov, B, seed, max_gap=6, p_seek=0.7, far_every=3):
+    """Episodes that END EARLY: two of three tasks are injected with every goal 1..max_gap cells from its start
+    (env.reset -> env.restart() on the injected task, as gen_rollout does) and every agent plays a goal-seeking action with
+    probability p_seek, the reference's own epsilon = 1 choice (np.random.choice, agent/agent.py:44-45) otherwise -- so episode
+    lengths differ, most episodes carry padded steps, and `terminated` fires before the limit.  Every third task is a random
+    far one played with a seek probability of 0.3 (most of those run to the episode limit: no padding, terminated at the last step).  The episode dicts are still the reference's own
+    RolloutWorker.generate_episode output (padding rules of common/rollout.py:131-141).  far_every=0: near tasks only, so that the
+    batch's own length (agent/agent.py:51-61) is below the episode limit -- the case where a host-side length bound
+    (Agents.train(max_len=)) makes the learn run over steps that are padded in EVERY episode."""
     np.random.seed(seed)
     torch.manual_seed(seed)
     import random
     random.seed(seed)
+    rng = np.random.default_rng(seed)
     env = DMFBenv(W, L, drop_num, 0, fov=fov)
     args = ref_args(drop_num, W, L, fov, env)
     agents = Agents(args)
     det_init(agents.policy.eval_rnn)
     det_init(agents.policy.target_rnn, salt=0.5)     # different target weights: exercises both nets
     worker = RolloutWorker(env, agents, args)
-    worker.epsilon = 0.6                             # mixed greedy / random episodes of varied length
-    episodes = [worker.generate_episode()[4] for _ in range(B)]
+    worker.epsilon = 1.0
+    rm = env.routing_manager
+    real_reset = env.reset
+    mode = {'inject': False}
+    env.reset = lambda new=False: env.restart() if mode['inject'] else real_reset(new)
+    ref_choice = agents.choose_action
+
+    def choose(obs, last_action, agent_num, avail_actions, epsilon, evaluate=False):
+        a = ref_choice(obs, last_action, agent_num, avail_actions, epsilon, evaluate)   # keeps the hidden-state bookkeeping
+        if rng.random() < (p_seek if mode['inject'] else 0.3):
+            dx, dy = int(obs[-2]), int(obs[-1])          # goal - position per axis (dmfb.py:441-453; the zoom keeps the sign)
+            opts = ([1] if dx > 0 else [2] if dx < 0 else []) + ([4] if dy > 0 else [3] if dy < 0 else [])
+            a = int(rng.choice(opts)) if opts else 0
+        return a
+    agents.choose_action = choose
+    episodes = []
+    for k in range(B):
+        mode['inject'] = (far_every == 0 or k % far_every != 0)
+        if mode['inject']:
+            st, en = near_task(rng, W, L, drop_num, max_gap)
+            rm.starts, rm.ends = st.copy(), en.copy()
+        episodes.append(worker.generate_episode()[4])
     batch = {k: np.concatenate([e[k] for e in episodes], axis=0) for k in episodes[0]}
     out = {k: (v.astype(np.int8) if k not in ('r',) else v.astype(np.float64)) for k, v in batch.items()}
     out['padded'] = batch['padded'].astype(np.uint8)
@@ -93,7 +142,8 @@ def gen_learn(tag, drop_num, W, L, fov, B, seed):
     out['cfg'] = np.array([W, L, drop_num, fov, args.hyper_hidden_dim, args.grad_norm_clip])
     path = os.path.join(OUT, 'vdn_learn_%s.npz' % tag)
     np.savez_compressed(path, **out)
-    print(os.path.basename(path), 'B=%d grad_norms=%s bytes=%d' % (B, norms, os.path.getsize(path)))
+    lens = (1 - out['padded'][:, :, 0].astype(int)).sum(1)
+    print(os.path.basename(path), 'B=%d valid steps per episode=%s grad_norms=%s bytes=%d' % (B, lens.tolist(), norms, os.path.getsize(path)))
 
 
 def gen_rollout(seed, n_tasks):
@@ -160,7 +210,8 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['small', 'b64', 'rollout', 'meda']
     if 'small' in which:
         gen_learn('4d_od24', 4, 10, 10, 9, B=6, seed=5)
-        gen_learn('10d_od32', 10, 20, 20, 9, B=3, seed=6)
+        gen_learn('10d_od32', 10, 20, 20, 9, B=5, seed=6)
+        gen_learn('4d_od24_short', 4, 10, 10, 9, B=6, seed=8, far_every=0)
     if 'b64' in which:
         # 64 episodes x T 40 x 4 droplets = 10 240 rows: crosses the build's split-K weight-gradient (>= 1024 rows), two-stage
         # column-sum (>= 2048 rows) and multi-block-per-workgroup conv-backward (> 2560 rows) thresholds
