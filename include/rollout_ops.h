@@ -82,6 +82,75 @@ int rollout_post_step(int32_t n_envs, int32_t episode_limit, int32_t t, uint8_t 
                       float *d_epsilon, float anneal, float min_epsilon, int32_t *d_n_alive, uint32_t *d_draw,
                       const int8_t *d_obs, int32_t obs_row_bytes, int8_t *d_ep_o, int8_t *d_ep_o_next, void *stream);
 
+/* ---- continuous rollout ("stream" mode) -------------------------------------------------------------------------------------
+ * The reference plays one chip: when its episode ends, generate_episode returns, the caller stores the episode
+ * (train.py:62-73) and calls generate_episode again, which resets the chip (common/rollout.py:101-112).  In the lock-step
+ * batch every chip does exactly that on its own clock: a chip whose episode ended in lock-step s starts its next episode in
+ * lock-step s + 1, and the finished episode is written into the replay ring (common/replay_buffer.py:33-46) on the device, so a
+ * round is a fixed number of lock-steps in which EVERY row is live, however short the policy's episodes are.
+ *
+ * rollout_stage: per-chip state of the episode being played (DEVICE pointers, caller-owned; zero-initialised):
+ *   d_t_ep int32[E]           step index inside the running episode
+ *   d_o0 int8[E][row]         its first observation;   d_o_next int8[E][T][row]  observation after each step (row = n * obs bytes)
+ *   d_u int8[E][T][n]         d_onehot int8[E][T][n][A]      d_r float32[E][T]
+ *   d_ep_acc float64[E][3]    running (reward, constraints, success) of the episode (rollout.py:122-124)
+ *   d_chip_acc int64[E][4]    += (episodes closed, their steps with the failure inflation of rollout.py:148-149, successes,
+ *                                 env steps played); the caller sums / clears them between rounds
+ *   d_close_slot int32[E]     written by rollout_stream_post: ring slot the chip's episode closes into this lock-step, or -1
+ * rollout_ring: the replay buffer's tensors (common/replay_buffer.py:10-28, `slots` episodes of T steps) plus
+ *   d_len int32[slots]        valid steps of the episode in each slot (0 = never written)
+ *   d_stats float64[slots][4] (reward, steps incl. failure inflation, constraints, success) = generate_episode's return values
+ *   d_state int64[4]          [0] next slot to write (ring cursor), [1] slots filled (current_size), [2] episodes closed so far
+ */
+typedef struct {
+    int32_t *d_t_ep;
+    int8_t *d_o0, *d_o_next, *d_u, *d_onehot;
+    float *d_r;
+    double *d_ep_acc;
+    int64_t *d_chip_acc;
+    int32_t *d_close_slot;
+} rollout_stage;
+
+typedef struct {
+    int32_t slots;
+    int8_t *d_o, *d_o_next, *d_u, *d_u_onehot, *d_avail_u, *d_avail_u_next;
+    float *d_r;
+    uint8_t *d_padded, *d_terminated;
+    int32_t *d_len;
+    double *d_stats;
+    int64_t *d_state;
+} rollout_ring;
+
+/* rollout_gru_head_select with every chip at its own step: the pick of row (e, a) is staged at d_stage_u[e][d_t_ep[e]][a]
+ * (and its one-hot alike) instead of one common slot t. */
+int rollout_gru_head_select_stream(const float *d_igates, const float *d_hgates, const float *d_b_ih, const float *d_b_hh, float *d_h,
+                                   const float *d_fc_w, const float *d_fc_b, int32_t n_envs, int32_t n_agents, int32_t hidden,
+                                   int32_t n_actions, const float *d_epsilon, int32_t evaluate, uint64_t seed, const uint32_t *d_draw,
+                                   int32_t *d_actions, int8_t *d_last_onehot, int8_t *d_stage_u, int8_t *d_stage_onehot,
+                                   int32_t episode_limit, const int32_t *d_t_ep, float *d_q, void *stream);
+
+/* After the transition of a lock-step (rollout.py:118-129), for every chip e at step t = d_t_ep[e] of its episode:
+ *   stage r[e][t] = team_reward[e]; the episode's running sums += this step's reward / constraints / success;
+ *   if d_term[e]: the episode closes into ring slot (cursor + k) % slots, k = rank of e among the chips closing in this lock-step
+ *   in ASCENDING chip order (deterministic); ring d_len / d_stats of the slot and the chip's counters are written, the running
+ *   sums cleared; d_close_slot[e] = that slot, else -1.  Then ring cursor / size / total advance, *d_epsilon = max(*d_epsilon -
+ *   anneal * n_envs, min_epsilon) (every chip played a step; epsilon_anneal_scale == 'step', rollout.py:126-127), *d_draw += 1.
+ * d_t_ep is NOT advanced here (rollout_stream_close does that). */
+int rollout_stream_post(int32_t n_envs, int32_t episode_limit, const rollout_ring *ring, const uint8_t *d_term,
+                        const double *d_team_reward, const void *d_constraints, int32_t constraints_f64, const uint8_t *d_success,
+                        const rollout_stage *stage, float *d_epsilon, float anneal, float min_epsilon, uint32_t *d_draw, void *stream);
+
+/* Then, per chip: o_next[e][t] = d_obs_new[e] is staged (and o0[e] = d_obs_prev[e] when t == 0: the observation the step was
+ * chosen from); a chip with d_close_slot[e] >= 0 writes its whole episode into that ring slot with the reference's padding
+ * (rollout.py:131-141: rows behind the end are zeros, padded = 1, terminated = 1, avail_u = avail_u_next = 0; o[t] = o0 for
+ * t == 0, o_next[t - 1] after), clears its rows of d_hidden (float32[E*n][hidden]; policy.init_hidden, rollout.py:112) and
+ * d_last_onehot (rollout.py:110) and sets d_t_ep[e] = 0; every other chip advances d_t_ep[e] by one.  The caller then resets the
+ * closed chips' env (dmfb_vec_reset / meda_vec_reset with d_term as mask), which also rewrites their rows of d_obs_new with the
+ * first observation of the next episode.  obs_row_bytes = n_agents * observation bytes. */
+int rollout_stream_close(int32_t n_envs, int32_t n_agents, int32_t n_actions, int32_t episode_limit, int32_t obs_row_bytes,
+                         int32_t hidden, const int8_t *d_obs_prev, const int8_t *d_obs_new, const rollout_stage *stage,
+                         const rollout_ring *ring, float *d_hidden, int8_t *d_last_onehot, void *stream);
+
 int rollout_last_hip_error(void);
 
 #ifdef __cplusplus

@@ -166,6 +166,21 @@ def crnn_ops():
     return lib
 
 
+class RolloutStage(C.Structure):
+    """include/rollout_ops.h: rollout_stage"""
+    _fields_ = [('d_t_ep', C.c_void_p), ('d_o0', C.c_void_p), ('d_o_next', C.c_void_p), ('d_u', C.c_void_p),
+                ('d_onehot', C.c_void_p), ('d_r', C.c_void_p), ('d_ep_acc', C.c_void_p), ('d_chip_acc', C.c_void_p),
+                ('d_close_slot', C.c_void_p)]
+
+
+class RolloutRing(C.Structure):
+    """include/rollout_ops.h: rollout_ring"""
+    _fields_ = [('slots', C.c_int32), ('d_o', C.c_void_p), ('d_o_next', C.c_void_p), ('d_u', C.c_void_p),
+                ('d_u_onehot', C.c_void_p), ('d_avail_u', C.c_void_p), ('d_avail_u_next', C.c_void_p), ('d_r', C.c_void_p),
+                ('d_padded', C.c_void_p), ('d_terminated', C.c_void_p), ('d_len', C.c_void_p), ('d_stats', C.c_void_p),
+                ('d_state', C.c_void_p)]
+
+
 def rollout_ops():
     """include/rollout_ops.h"""
     lib = load('rollout_ops')
@@ -177,6 +192,10 @@ def rollout_ops():
     lib.rollout_gru_head_select_live.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, u64, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     lib.rollout_compact_alive.argtypes = [i32, vp, vp, vp, vp]
     lib.rollout_post_step.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp]
+    lib.rollout_gru_head_select_stream.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, u64, vp, vp, vp, vp, vp, i32, vp, vp, vp]
+    ringp, stagep = C.POINTER(RolloutRing), C.POINTER(RolloutStage)
+    lib.rollout_stream_post.argtypes = [i32, i32, ringp, vp, vp, vp, i32, vp, stagep, vp, f32, f32, vp, vp]
+    lib.rollout_stream_close.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, stagep, ringp, vp, vp, vp]
     lib.rollout_last_hip_error.argtypes = []
     lib._typed = True
     return lib

@@ -13,7 +13,15 @@ Book-keeping kept from the reference:
   * padding: zeros, padded = 1, terminated = 1 after the end of an episode (rollout.py:131-141)
   * `steps` is forced to `episode_limit` for unsuccessful episodes (rollout.py:60-61,148-149)
   * epsilon anneals per env-step: one lock-step of k live chips anneals k steps (rollout.py:126-127)
+
+Continuous mode (`RolloutWorker.generate_steps`, the Trainer's default on the GPU): every chip plays on its own clock -- a chip
+whose episode ended starts its next one in the following lock-step, and the finished episode is written into the replay ring
+on the device (include/rollout_ops.h, "stream" entry points).  A round is then a fixed number of lock-steps in which every
+(chip, droplet) row is live, whatever the length of the policy's episodes; the episodes in the ring are, one by one, what
+`generate_episode` of the reference returns (tests/test_gpu_rollout_stream.py replays them through the CPU oracle).
 """
+import types
+
 import torch
 
 
@@ -230,11 +238,16 @@ class Evaluator:
         """`task_num` consecutive greedy episodes on every chip (the chips keep ageing between
         episodes, as the single reference chip does); means over all chips and episodes."""
         tot = [0.0, 0.0, 0.0, 0.0]
+        keep = self.live_share  # the greedy episodes have their own live share; the training rollouts' statistic is put back
+        self.live_share = getattr(self, '_eval_live_share', 1.0)
         for _ in range(task_num):
             out = self._generate_episode()
             self.note_played(int(self.last_played.item()))
             for k in range(4):
                 tot[k] += float(out[k].double().mean().item())
+        self._eval_live_share, self.live_share = self.live_share, keep
+        if hasattr(self, 'stream_restart'):
+            self.stream_restart()
         return tuple(v / task_num for v in tot)
 
 
@@ -259,3 +272,146 @@ class RolloutWorker(Evaluator):
         reward, steps, constraints, success, episode, epsilon = play(epsilon, evaluate=False, record=True)
         self.epsilon = epsilon.clone() if self.use_graph else epsilon
         return reward, steps, constraints, success, episode
+
+    # ------------------------------------------------------------------ continuous rollout (every row live)
+    def stream_ok(self):
+        """The continuous rollout needs the fused lock-step tail (HIP conv front end + rollout_gru_head_select: hidden 128, the
+        reference's CRNN) and a GPU env; anything else keeps the episode-per-round form."""
+        net = self.agents.policy.eval_rnn
+        probe = torch.zeros((1, self.env.obs_len), dtype=torch.int8, device=self.device)
+        with torch.no_grad():
+            return bool(self.fuse_tail and self.device.type == 'cuda' and hasattr(net, 'act_ok') and net.act_ok(probe)
+                        and self.agents.args.rnn_hidden_dim == 128 and net.fc1.weight.is_contiguous()
+                        and self.epsilon_anneal_scale == 'step')
+
+    def _stream_state(self, buffer):
+        st = getattr(self, '_stream', None)
+        if st is not None and st.buffer is buffer:
+            return st
+        import ctypes as C
+        from .. import _lib
+        E, n, A, T, O, dev = self.n_envs, self.n_agents, self.n_actions, self.episode_limit, self.env.obs_len, self.device
+        if buffer.episode_limit != T or buffer.obs_shape != O or buffer.device != dev:
+            raise ValueError('replay buffer does not match the env (episode_limit / obs / device)')
+        st = types.SimpleNamespace(buffer=buffer, started=False, graphs={})
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        # the observation is double-buffered: the transition of lock-step s reads obs[s & 1] (through the Q-network) and writes
+        # obs[(s + 1) & 1], so that the first observation of an episode is still there when its first step is staged
+        st.obs = [z((E, n, O), torch.int8), z((E, n, O), torch.int8)]
+        st.out = []
+        for k in range(2):
+            o = type(self.env._out)()
+            C.memmove(C.byref(o), C.byref(self.env._out), C.sizeof(o))
+            o.d_obs = st.obs[k].data_ptr()
+            st.out.append(o)
+        st.hidden = z((E * n, self.agents.args.rnn_hidden_dim), torch.float32)
+        st.last_action = z((E, n, A), torch.int8)
+        st.actions = z((E, n), torch.int32)
+        st.t_ep = z((E,), torch.int32)
+        st.o0, st.o_next = z((E, n * O), torch.int8), z((E, T, n * O), torch.int8)
+        st.u, st.onehot, st.r = z((E, T, n), torch.int8), z((E, T, n, A), torch.int8), z((E, T), torch.float32)
+        st.ep_acc, st.chip_acc = z((E, 3), torch.float64), z((E, 4), torch.int64)
+        st.close_slot = torch.full((E,), -1, dtype=torch.int32, device=dev)
+        st.eps = z((1,), torch.float32)
+        st.stage = _lib.RolloutStage(st.t_ep.data_ptr(), st.o0.data_ptr(), st.o_next.data_ptr(), st.u.data_ptr(), st.onehot.data_ptr(),
+                                     st.r.data_ptr(), st.ep_acc.data_ptr(), st.chip_acc.data_ptr(), st.close_slot.data_ptr())
+        st.ring = buffer.ring_struct()
+        self._stream = st
+        return st
+
+    def stream_restart(self):
+        """Forget the episodes in flight: the next generate_steps resets every chip first (called after anything else -- a greedy
+        evaluation, generate_episode -- has used the env)."""
+        st = getattr(self, '_stream', None)
+        if st is not None:
+            st.started = False
+
+    @torch.no_grad()
+    def _play_stream(self, st, K):
+        """K lock-steps of every chip: Q-network (front end, the two GRU GEMMs, gate math + fc1 + epsilon-greedy), the env
+        transition, rollout_stream_post / rollout_stream_close, reset of the chips whose episode ended."""
+        import ctypes as C
+        E, n, A, T = self.n_envs, self.n_agents, self.n_actions, self.episode_limit
+        lib = self._ops()
+        vp = C.c_void_p
+        dev = self.device
+        stream = vp(torch.cuda.current_stream(dev).cuda_stream)
+        net = self.agents.policy.eval_rnn
+        env = self.env
+        if not st.started:   # (outside the captured graph: the warm-up call comes first)
+            if self.reset_fn is None:
+                env.reset(obs=st.obs[0])
+            else:
+                st.obs[0].copy_(self.reset_fn())
+            for t_ in (st.hidden, st.last_action, st.t_ep, st.ep_acc, st.chip_acc):
+                t_.zero_()
+            st.started = True
+        anneal = float(self.anneal_epsilon)
+        w_ih_pad = net.refresh_padded()
+        cons_f64 = None
+        for s in range(K):
+            cur, nxt = st.obs[s & 1], st.obs[(s + 1) & 1]
+            ig, hg = net.act_gates(cur.view(E * n, -1), st.last_action.view(E * n, -1), st.hidden, w_ih_pad)
+            rc = lib.rollout_gru_head_select_stream(vp(ig.data_ptr()), vp(hg.data_ptr()), vp(net.rnn.bias_ih.data_ptr()),
+                                                    vp(net.rnn.bias_hh.data_ptr()), vp(st.hidden.data_ptr()), vp(net.fc1.weight.data_ptr()),
+                                                    vp(net.fc1.bias.data_ptr()), E, n, st.hidden.shape[1], A, vp(st.eps.data_ptr()), 0,
+                                                    self.rng_seed, vp(self._draw.data_ptr()), vp(st.actions.data_ptr()),
+                                                    vp(st.last_action.data_ptr()), vp(st.u.data_ptr()), vp(st.onehot.data_ptr()), T,
+                                                    vp(st.t_ep.data_ptr()), None, stream)
+            if rc != 0:
+                raise RuntimeError('rollout_gru_head_select_stream failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
+            u = self.uniforms_fn(s) if self.uniforms_fn is not None else None
+            _, _, _, info = env.step(st.actions, uniforms=u, record=True, out=st.out[(s + 1) & 1])
+            cons = info['constraints']
+            cons_f64 = int(cons.dtype == torch.float64)
+            rc = lib.rollout_stream_post(E, T, C.byref(st.ring), vp(info['terminated'].data_ptr()), vp(info['team_reward'].data_ptr()),
+                                         vp(cons.data_ptr()), cons_f64, vp(info['success'].data_ptr()), C.byref(st.stage),
+                                         vp(st.eps.data_ptr()), anneal, float(self.min_epsilon), vp(self._draw.data_ptr()), stream)
+            if rc == 0:
+                rc = lib.rollout_stream_close(E, n, A, T, n * env.obs_len, st.hidden.shape[1], vp(cur.data_ptr()), vp(nxt.data_ptr()),
+                                              C.byref(st.stage), C.byref(st.ring), vp(st.hidden.data_ptr()),
+                                              vp(st.last_action.data_ptr()), stream)
+            if rc != 0:
+                raise RuntimeError('rollout_stream_post/close failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
+            if self.stream_step_hook is not None:   # tests: (lock-step, actions, terminated) before the chips are reset
+                self.stream_step_hook(s, st.actions, info['terminated'])
+            env.reset(mask=info['terminated'], obs=nxt)   # reset(new=False) of the chips whose episode ended (rollout.py:103)
+        if K & 1:
+            st.obs[0].copy_(st.obs[1])
+
+    stream_step_hook = None
+
+    def generate_steps(self, buffer, n_steps=None):
+        """`n_steps` lock-steps (default: episode_limit) of every chip, episodes that end on the way written into `buffer`'s ring
+        (include/rollout_ops.h).  Returns a device tensor int64[4]: episodes closed in this call, their step count with the
+        failure inflation of rollout.py:148-149 (what train.py:65 adds to time_steps), successes, env steps played."""
+        K = int(n_steps or self.episode_limit)
+        st = self._stream_state(buffer)
+        self._ops()
+        if not st.started:
+            st.eps.copy_(torch.as_tensor(self.epsilon, dtype=torch.float32, device=self.device).reshape(1))
+        if self.use_graph and self.uniforms_fn is None and self.stream_step_hook is None:
+            g = st.graphs.get(K)
+            if g is None:
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):  # warm-up outside capture; these K lock-steps count like any others
+                    self._play_stream(st, K)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                self._capturing = True
+                try:
+                    with torch.cuda.graph(g):
+                        self._play_stream(st, K)
+                finally:
+                    self._capturing = False
+                st.graphs[K] = g
+            else:
+                g.replay()
+        else:
+            self._play_stream(st, K)
+        out = st.chip_acc.sum(0)
+        st.chip_acc.zero_()
+        self.epsilon = st.eps[0].clone()
+        return out

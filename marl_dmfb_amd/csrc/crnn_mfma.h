@@ -153,11 +153,13 @@ __global__ __launch_bounds__(64 * NW) void k_conv9_mfma(const int8_t *__restrict
         if (tid < 10) s_mlp[10 * G::VEC + tid] = mlp_b[tid];
     }
     // cr / rows_per_chip as a multiply-high (exact for cr * rows_per_chip < 2^32: the host checks the row count)
-    const uint32_t rpc_magic = (uint32_t)(0x100000000ull / (uint32_t)(rows_per_chip > 0 ? rows_per_chip : 1)) + 1u;
+    // one row per chip (drop_num = 1): 2^32 / 1 does not fit the 32-bit magic -- the quotient is cr itself
+    const uint32_t rpc = (uint32_t)(rows_per_chip > 0 ? rows_per_chip : 1);
+    const uint32_t rpc_magic = rpc > 1 ? (uint32_t)(0x100000000ull / rpc) + 1u : 0u;
     auto src_row = [&](long cr) -> long {  // compact row -> row of the input tensors
         if (!live_chips) return cr;
-        const uint32_t k = __umulhi((uint32_t)cr, rpc_magic);
-        return (long)((uint32_t)live_chips[k] * (uint32_t)rows_per_chip + ((uint32_t)cr - k * (uint32_t)rows_per_chip));
+        const uint32_t k = rpc > 1 ? __umulhi((uint32_t)cr, rpc_magic) : (uint32_t)cr;
+        return (long)((uint32_t)live_chips[k] * rpc + ((uint32_t)cr - k * rpc));
     };
     // The bytes of block i+1 are fetched into registers while block i is in conv1 and parked in LDS once conv1 is
     // done with s_in: the HBM latency of the int8 rows never sits between two barriers.  A WAVE fetches whole rows (rows

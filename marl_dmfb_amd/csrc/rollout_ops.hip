@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void k_gru_head_select(const float *__restrict
                                                          const uint32_t *__restrict__ draw_p, int32_t *__restrict__ actions,
                                                          int8_t *__restrict__ last_onehot, int8_t *__restrict__ ep_u, int8_t *__restrict__ ep_onehot,
                                                          int T, int t, float *__restrict__ q_out,
-                                                         const int32_t *__restrict__ live_chips, const int32_t *__restrict__ n_live) {
+                                                         const int32_t *__restrict__ live_chips, const int32_t *__restrict__ n_live,
+                                                         const int32_t *__restrict__ t_ep) {
     constexpr int H = 128;
     const int l32 = threadIdx.x & 31;
     // live_chips != NULL: only the rows of the listed chips; the x-side gates `ig` are COMPACT (row k*n + a of ig belongs to row
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void k_gru_head_select(const float *__restrict
     for (int k = 0; k < A; ++k) lo[k] = (int8_t)(k == act);
     if (ep_u) {
         const int e = r / n, a = r - e * n;
+        if (t_ep) t = t_ep[e];   // continuous rollout: every chip is at its own step of its own episode
         const size_t slot = ((size_t)e * T + t) * n + a;
         ep_u[slot] = (int8_t)act;
         if (ep_onehot) {
@@ -229,6 +231,145 @@ __global__ __launch_bounds__(kPostBlock) void k_post(int E, int T, int t, uint8_
     }
 }
 
+// ---- continuous rollout (include/rollout_ops.h, "stream" entry points) --------------------------------------------------------
+// k_stream_post: ONE workgroup walks the chips in chunks of its size (4096 chips = four chunks), so that the ring slots of the
+// episodes that end in this lock-step are handed out in chip order by a block-wide scan: the ring's content does not depend on
+// scheduling (graph replay == eager play, bit for bit).
+constexpr int kStreamBlock = 1024;
+__global__ __launch_bounds__(kStreamBlock) void k_stream_post(int E, int T, int S, const uint8_t *__restrict__ term, const double *__restrict__ team_reward,
+                                                             const void *__restrict__ constraints, int cons_f64, const uint8_t *__restrict__ success,
+                                                             const int32_t *__restrict__ t_ep, float *__restrict__ stage_r, double *__restrict__ ep_acc,
+                                                             int64_t *__restrict__ chip_acc, int64_t *__restrict__ ring_state,
+                                                             int32_t *__restrict__ close_slot, int32_t *__restrict__ ring_len,
+                                                             double *__restrict__ ring_stats, float *__restrict__ eps_p, float anneal, float min_eps,
+                                                             uint32_t *__restrict__ draw_p) {
+    __shared__ int s_wave[kStreamBlock / 64];
+    __shared__ long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long cursor0 = ring_state[0];
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int e0 = 0; e0 < E; e0 += kStreamBlock) {
+        const int e = e0 + tid;
+        const bool in = e < E;
+        const bool tm = in && term[e] != 0;
+        double rew = 0.0, cons = 0.0, succ = 0.0;
+        int t = 0;
+        if (in) {
+            t = t_ep[e];
+            const double tr = team_reward[e];
+            stage_r[(size_t)e * T + t] = (float)tr;
+            rew = ep_acc[(size_t)e * 3] + tr;
+            cons = ep_acc[(size_t)e * 3 + 1] + (cons_f64 ? ((const double *)constraints)[e] : (double)((const int32_t *)constraints)[e]);
+            succ = ep_acc[(size_t)e * 3 + 2] + (double)success[e];
+            ep_acc[(size_t)e * 3] = tm ? 0.0 : rew;
+            ep_acc[(size_t)e * 3 + 1] = tm ? 0.0 : cons;
+            ep_acc[(size_t)e * 3 + 2] = tm ? 0.0 : succ;
+            chip_acc[(size_t)e * 4 + 3] += 1;   // env steps played
+        }
+        const unsigned long long m = __ballot(tm);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        long off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (in) {
+            int slot = -1;
+            if (tm) {
+                slot = (int)((cursor0 + off + rank) % S);
+                const int len = t + 1;
+                const long infl = succ > 0.0 ? len : T;   // `steps` is forced to episode_limit when not successful (rollout.py:148-149)
+                ring_len[slot] = len;
+                ring_stats[(size_t)slot * 4] = rew;
+                ring_stats[(size_t)slot * 4 + 1] = (double)infl;
+                ring_stats[(size_t)slot * 4 + 2] = cons;
+                ring_stats[(size_t)slot * 4 + 3] = succ;
+                chip_acc[(size_t)e * 4] += 1;
+                chip_acc[(size_t)e * 4 + 1] += infl;
+                chip_acc[(size_t)e * 4 + 2] += succ > 0.0 ? 1 : 0;
+            }
+            close_slot[e] = slot;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < kStreamBlock / 64; ++w) tot += s_wave[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const long closed = s_base;
+        ring_state[0] = (cursor0 + closed) % S;
+        ring_state[1] = min((long)S, ring_state[1] + closed);
+        ring_state[2] += closed;
+        if (anneal > 0.0f) *eps_p = fmaxf(*eps_p - anneal * (float)E, min_eps);   // every chip played a step (rollout.py:126-127)
+        if (draw_p) *draw_p += 1u;
+    }
+}
+
+struct RingPtrs {
+    int8_t *o, *o_next, *u, *u_onehot, *avail_u, *avail_u_next;
+    float *r;
+    uint8_t *padded, *terminated;
+};
+
+// One workgroup per chip.  (1) the chip's row of this lock-step is appended to its staged episode; (2) if its episode ended, the
+// staged episode is written into its ring slot with the padding rules of rollout.py:131-141 (zeros, padded = terminated = 1,
+// avail 0 behind the end), and the chip's recurrent state is cleared for the next episode (policy.init_hidden, rollout.py:112).
+template <typename V>
+__global__ __launch_bounds__(256) void k_stream_close(int E, int n, int A, int T, int row_v, int H, const V *__restrict__ obs_prev,
+                                                      const V *__restrict__ obs_new, const int32_t *__restrict__ close_slot,
+                                                      int32_t *__restrict__ t_ep, V *__restrict__ stage_o0, V *__restrict__ stage_o_next,
+                                                      const int8_t *__restrict__ stage_u, const int8_t *__restrict__ stage_onehot,
+                                                      const float *__restrict__ stage_r, RingPtrs ring, float *__restrict__ hidden,
+                                                      int8_t *__restrict__ last_onehot) {
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int t = t_ep[e], slot = close_slot[e];
+    const V *on = obs_new + (size_t)e * row_v, *op = obs_prev + (size_t)e * row_v;
+    V *so = stage_o_next + (size_t)e * T * row_v;
+    for (int k = tid; k < row_v; k += 256) {
+        so[(size_t)t * row_v + k] = on[k];
+        if (t == 0) stage_o0[(size_t)e * row_v + k] = op[k];
+    }
+    __syncthreads();  // t_ep[e] / close_slot[e] were read by every thread before thread 0 rewrites t_ep
+    if (slot < 0) {
+        if (tid == 0) t_ep[e] = t + 1;
+        return;
+    }
+    const int len = t + 1;
+    // o[tt] = first observation (tt == 0) or o_next[tt - 1]; o_next[tt] as staged; this step's row comes from obs_new (the
+    // staged copy above was written by other threads of this workgroup)
+    V *ro = (V *)ring.o + (size_t)slot * T * row_v, *rn = (V *)ring.o_next + (size_t)slot * T * row_v;
+    const V *o0 = t == 0 ? op : stage_o0 + (size_t)e * row_v;
+    for (int i = tid; i < T * row_v; i += 256) {
+        const int tt = i / row_v, k = i - tt * row_v;
+        V vo = 0, vn = 0;
+        if (tt < len) {
+            vn = tt == t ? on[k] : so[(size_t)tt * row_v + k];
+            vo = tt == 0 ? o0[k] : so[(size_t)(tt - 1) * row_v + k];
+        }
+        ro[i] = vo;
+        rn[i] = vn;
+    }
+    for (int i = tid; i < T * n * A; i += 256) {
+        const int tt = i / (n * A);
+        const int8_t live = (int8_t)(tt < len);
+        ring.u_onehot[(size_t)slot * T * n * A + i] = live ? stage_onehot[(size_t)e * T * n * A + i] : (int8_t)0;
+        ring.avail_u[(size_t)slot * T * n * A + i] = live;
+        ring.avail_u_next[(size_t)slot * T * n * A + i] = live;
+    }
+    for (int i = tid; i < T * n; i += 256) ring.u[(size_t)slot * T * n + i] = i / n < len ? stage_u[(size_t)e * T * n + i] : (int8_t)0;
+    for (int tt = tid; tt < T; tt += 256) {
+        ring.r[(size_t)slot * T + tt] = tt < len ? stage_r[(size_t)e * T + tt] : 0.0f;
+        ring.padded[(size_t)slot * T + tt] = (uint8_t)(tt >= len);
+        ring.terminated[(size_t)slot * T + tt] = (uint8_t)(tt >= len - 1);
+    }
+    for (int i = tid; i < n * H; i += 256) hidden[(size_t)e * n * H + i] = 0.0f;
+    for (int i = tid; i < n * A; i += 256) last_onehot[(size_t)e * n * A + i] = 0;
+    if (tid == 0) t_ep[e] = 0;
+}
+
 thread_local int g_last = 0;
 
 int finish() {
@@ -265,10 +406,11 @@ static int gru_head_select_impl(const float *d_igates, const float *d_hgates, co
                                 const float *d_fc_w, const float *d_fc_b, int32_t n_envs, int32_t n_agents, int32_t hidden,
                                 int32_t n_actions, const float *d_epsilon, int32_t evaluate, uint64_t seed, const uint32_t *d_draw,
                                 int32_t *d_actions, int8_t *d_last_onehot, int8_t *d_ep_u, int8_t *d_ep_onehot, int32_t episode_limit,
-                                int32_t t, float *d_q, const int32_t *d_live_chips, const int32_t *d_n_live, void *stream) {
+                                int32_t t, float *d_q, const int32_t *d_live_chips, const int32_t *d_n_live, void *stream,
+                                const int32_t *d_t_ep = nullptr) {
     if (!d_igates || !d_hgates || !d_b_ih || !d_b_hh || !d_h || !d_fc_w || !d_fc_b || !d_actions || !d_last_onehot || n_envs < 0 ||
         n_agents < 1 || hidden != 128 || n_actions < 1 || n_actions > 16 || (!evaluate && (!d_epsilon || !d_draw)) ||
-        (d_ep_u && (t < 0 || t >= episode_limit)) || ((d_live_chips == nullptr) != (d_n_live == nullptr)))
+        (d_ep_u && !d_t_ep && (t < 0 || t >= episode_limit)) || ((d_live_chips == nullptr) != (d_n_live == nullptr)))
         return ROLLOUT_ERR_BAD_ARG;
     const long rows = (long)n_envs * n_agents;
     if (rows == 0) return ROLLOUT_OK;
@@ -277,7 +419,7 @@ static int gru_head_select_impl(const float *d_igates, const float *d_hgates, co
     hipLaunchKernelGGL(k_gru_head_select, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, d_igates, d_hgates, d_b_ih,
                        d_b_hh, d_h, d_fc_w, d_fc_b, (int)rows, n_agents, n_actions, d_epsilon, evaluate, (uint32_t)seed,
                        (uint32_t)(seed >> 32), d_draw, d_actions, d_last_onehot, d_ep_u, d_ep_onehot, episode_limit, t, d_q,
-                       d_live_chips, d_n_live);
+                       d_live_chips, d_n_live, d_t_ep);
     return finish();
 }
 
@@ -336,6 +478,59 @@ int rollout_post_step(int32_t n_envs, int32_t episode_limit, int32_t t, uint8_t 
     hipLaunchKernelGGL(k_post, dim3((unsigned)((n_envs + kPostBlock - 1) / kPostBlock)), dim3(kPostBlock), 0, (hipStream_t)stream, n_envs, episode_limit, t, d_alive, d_term, d_team_reward,
                        d_constraints, constraints_f64, d_success, d_ep_r, d_ep_padded, d_ep_terminated, d_sum_reward, d_sum_constraints,
                        d_sum_success, d_steps, d_epsilon, anneal, min_epsilon, d_n_alive, d_draw);
+    return finish();
+}
+
+int rollout_gru_head_select_stream(const float *d_igates, const float *d_hgates, const float *d_b_ih, const float *d_b_hh, float *d_h,
+                                   const float *d_fc_w, const float *d_fc_b, int32_t n_envs, int32_t n_agents, int32_t hidden,
+                                   int32_t n_actions, const float *d_epsilon, int32_t evaluate, uint64_t seed, const uint32_t *d_draw,
+                                   int32_t *d_actions, int8_t *d_last_onehot, int8_t *d_stage_u, int8_t *d_stage_onehot,
+                                   int32_t episode_limit, const int32_t *d_t_ep, float *d_q, void *stream) {
+    if (!d_t_ep || !d_stage_u) return ROLLOUT_ERR_BAD_ARG;
+    return gru_head_select_impl(d_igates, d_hgates, d_b_ih, d_b_hh, d_h, d_fc_w, d_fc_b, n_envs, n_agents, hidden, n_actions, d_epsilon,
+                                evaluate, seed, d_draw, d_actions, d_last_onehot, d_stage_u, d_stage_onehot, episode_limit, 0, d_q, nullptr,
+                                nullptr, stream, d_t_ep);
+}
+
+int rollout_stream_post(int32_t n_envs, int32_t episode_limit, const rollout_ring *ring, const uint8_t *d_term,
+                        const double *d_team_reward, const void *d_constraints, int32_t constraints_f64, const uint8_t *d_success,
+                        const rollout_stage *stage, float *d_epsilon, float anneal, float min_epsilon, uint32_t *d_draw, void *stream) {
+    if (!ring || !stage || !d_term || !d_team_reward || !d_constraints || !d_success || n_envs < 0 || episode_limit < 1 ||
+        ring->slots < 1 || !ring->d_len || !ring->d_stats || !ring->d_state || !stage->d_t_ep || !stage->d_r || !stage->d_ep_acc ||
+        !stage->d_chip_acc || !stage->d_close_slot || (anneal > 0.0f && !d_epsilon))
+        return ROLLOUT_ERR_BAD_ARG;
+    if (n_envs == 0) return ROLLOUT_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_stream_post, dim3(1), dim3(kStreamBlock), 0, (hipStream_t)stream, n_envs, episode_limit, ring->slots, d_term,
+                       d_team_reward, d_constraints, constraints_f64, d_success, stage->d_t_ep, stage->d_r, stage->d_ep_acc,
+                       stage->d_chip_acc, ring->d_state, stage->d_close_slot, ring->d_len, ring->d_stats, d_epsilon, anneal, min_epsilon,
+                       d_draw);
+    return finish();
+}
+
+int rollout_stream_close(int32_t n_envs, int32_t n_agents, int32_t n_actions, int32_t episode_limit, int32_t obs_row_bytes,
+                         int32_t hidden, const int8_t *d_obs_prev, const int8_t *d_obs_new, const rollout_stage *stage,
+                         const rollout_ring *ring, float *d_hidden, int8_t *d_last_onehot, void *stream) {
+    if (!ring || !stage || !d_obs_prev || !d_obs_new || !d_hidden || !d_last_onehot || n_envs < 0 || n_agents < 1 || n_actions < 1 ||
+        episode_limit < 1 || obs_row_bytes < 1 || hidden < 1 || !stage->d_t_ep || !stage->d_close_slot || !stage->d_o0 ||
+        !stage->d_o_next || !stage->d_u || !stage->d_onehot || !stage->d_r || !ring->d_o || !ring->d_o_next || !ring->d_u ||
+        !ring->d_u_onehot || !ring->d_avail_u || !ring->d_avail_u_next || !ring->d_r || !ring->d_padded || !ring->d_terminated)
+        return ROLLOUT_ERR_BAD_ARG;
+    if (n_envs == 0) return ROLLOUT_OK;
+    const RingPtrs rp{ring->d_o, ring->d_o_next, ring->d_u, ring->d_u_onehot, ring->d_avail_u, ring->d_avail_u_next, ring->d_r,
+                      ring->d_padded, ring->d_terminated};
+    const bool dw = obs_row_bytes % 4 == 0 &&
+                    ((size_t)d_obs_prev | (size_t)d_obs_new | (size_t)stage->d_o0 | (size_t)stage->d_o_next | (size_t)ring->d_o | (size_t)ring->d_o_next) % 4 == 0;
+    (void)hipGetLastError();
+    if (dw)
+        hipLaunchKernelGGL((k_stream_close<uint32_t>), dim3((unsigned)n_envs), dim3(256), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
+                           episode_limit, obs_row_bytes / 4, hidden, (const uint32_t *)d_obs_prev, (const uint32_t *)d_obs_new,
+                           stage->d_close_slot, stage->d_t_ep, (uint32_t *)stage->d_o0, (uint32_t *)stage->d_o_next, stage->d_u,
+                           stage->d_onehot, stage->d_r, rp, d_hidden, d_last_onehot);
+    else
+        hipLaunchKernelGGL((k_stream_close<int8_t>), dim3((unsigned)n_envs), dim3(256), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
+                           episode_limit, obs_row_bytes, hidden, d_obs_prev, d_obs_new, stage->d_close_slot, stage->d_t_ep, stage->d_o0,
+                           stage->d_o_next, stage->d_u, stage->d_onehot, stage->d_r, rp, d_hidden, d_last_onehot);
     return finish();
 }
 

@@ -40,13 +40,75 @@ class Trainer:
         self._time_steps = 0
         self._pending_steps = None  # data parallel: the reduced step count of the last round, still on the device
         self.trained_times = 0
-        self.len_bound = 0  # longest episode stored so far (first terminated step + 1), kept on the host
+        self.len_bound = 0  # longest episode the buffer currently holds (first terminated step + 1), kept on the host
+        self._round_lens = []  # episode-per-round mode: longest episode of each round still in the ring buffer
+        # Continuous rollout (common/rollout.py: generate_steps): a round is `round_steps` lock-steps (default episode_limit) in
+        # which every chip plays all the time; episodes go into the ring on the device as they end.  Default on the GPU when the
+        # fused lock-step tail applies; args.stream=False keeps one episode per chip per round (the reference's generate_episode
+        # batched, with the finished chips idle until the slowest one is done).
+        stream = getattr(args, 'stream', None)
+        self.stream = bool(self.rolloutWorker.use_graph and self.rolloutWorker.stream_ok()) if stream is None else bool(stream)
+        self.last_round = {}
         self.dist = bool(self.agents.policy.dist)
         self.rank = torch.distributed.get_rank() if self.dist else 0
         self.saves = []  # (time_steps, evaluate index or None) of every checkpoint written, for tests/logs
 
+    def _collect_and_learn_stream(self):
+        """One round in continuous mode: `round_steps` lock-steps of every chip (episodes close into the ring on the way), ONE
+        device read (ring cursor / fill level / episode lengths + the round's counters), then `train_time` learns whose episodes
+        are drawn on the host -- so each learn is handed its exact length (agent/agent.py:51-61) without reading anything back."""
+        w, pol = self.rolloutWorker, self.agents.policy
+        T = self.args.episode_limit
+        K = int(getattr(self.args, 'round_steps', None) or T)
+        acc = w.generate_steps(self.buffer, K)
+        closed, inflated, succ, played = self.buffer.sync_host(acc)
+        self.last_round = {'episodes': closed, 'success': succ, 'steps_inflated': inflated, 'played': played}
+        if self.dist:
+            if K < T:
+                raise RuntimeError('data parallel: round_steps must be >= episode_limit (every rank must hold an episode to learn from)')
+            local = torch.tensor([inflated // 4096, inflated % 4096], dtype=torch.float32, device=w.device)
+            pol.ride_along, pol.ride_along_sum = local, None
+        learns = self.args.train_time if self.buffer.current_size > 0 else 0
+        k_batch = min(self.buffer.current_size, self.args.batch_size)
+        draws = [self.buffer.draw(k_batch) for _ in range(learns)]   # host RNG: the order of the draws is fixed here
+        prefetched = []
+        for k in range(learns):
+            idx, lens = draws[k]
+            mini_batch = prefetched.pop() if prefetched else self.buffer.gather(idx)
+            if self.dist and k + 1 < learns and getattr(self.args, 'prefetch_sample', True):
+                nxt = draws[k + 1][0]
+                pol.overlap_hook = lambda nxt=nxt: prefetched.append(self.buffer.gather(nxt))
+            self.agents.train(mini_batch, self.trained_times, max_len=int(lens[0]))
+            pol.overlap_hook = None
+            self.trained_times += 1
+        if self.dist:
+            self._finish_dist_round(pol)
+        else:
+            self._time_steps += inflated
+        return played
+
+    def _finish_dist_round(self, pol):
+        if pol.ride_along_sum is None:  # no learn ran this round (train_time == 0): reduce the count by itself
+            pol.ride_along_sum = pol.all_reduce_sum(pol.ride_along)
+            pol.ride_along = None
+        self._flush_steps()
+        # copied to the host behind this round's learns without blocking; read when somebody asks for time_steps
+        # (run() does, every round), by when the copy of a loop that does not ask (bench.py) has long finished
+        src = pol.ride_along_sum
+        if src.is_cuda:
+            host = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+            host.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending_steps = (host, ev)
+        else:
+            self._pending_steps = (src, None)
+
     def collect_and_learn(self):
         """One round of the outer loop (train.py:59-78).  Returns env steps played this round (this rank)."""
+        if self.stream:
+            return self._collect_and_learn_stream()
+        self.rolloutWorker.stream_restart()
         _, steps, _, success, episode = self.rolloutWorker.generate_episode()
         local = steps.sum()  # failure-inflated count, as train.py:65
         # ONE device read per round: the steps played, the episode length the learns have to cover, and the step count.  Nothing
@@ -55,7 +117,10 @@ class Trainer:
                                                                      Agents.first_terminated_bound(episode['terminated']), local]).tolist())
         self.rolloutWorker.note_played(played)  # decides whether the next rollout keeps finished chips out of the Q-network
         self.buffer.store_episode(episode)
-        self.len_bound = max(self.len_bound, round_len)  # >= _get_max_episode_len of any batch sampled from the buffer
+        # the bound covers what the ring buffer holds NOW: a round's longest episode counts until the round has been overwritten
+        self._round_lens.append(round_len)
+        del self._round_lens[:-max(1, -(-self.buffer.size // max(1, self.env.n_envs)))]
+        self.len_bound = max(self._round_lens)  # >= _get_max_episode_len of any batch sampled from the buffer
         max_len = self.len_bound if getattr(self.args, 'host_len_bound', True) else None
         pol = self.agents.policy
         if self.dist:  # this rank's count travels with the gradients of the first learn (two exactly representable floats)
@@ -73,21 +138,7 @@ class Trainer:
             pol.overlap_hook = None
             self.trained_times += 1
         if self.dist:
-            if pol.ride_along_sum is None:  # no learn ran this round (train_time == 0): reduce the count by itself
-                pol.ride_along_sum = pol.all_reduce_sum(pol.ride_along)
-                pol.ride_along = None
-            self._flush_steps()
-            # copied to the host behind this round's learns without blocking; read when somebody asks for time_steps
-            # (run() does, every round), by when the copy of a loop that does not ask (bench.py) has long finished
-            src = pol.ride_along_sum
-            if src.is_cuda:
-                host = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
-                host.copy_(src, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                self._pending_steps = (host, ev)
-            else:
-                self._pending_steps = (src, None)
+            self._finish_dist_round(pol)
         else:
             self._time_steps += local_host
         return played
@@ -116,10 +167,12 @@ class Trainer:
     def _evaluate_and_record(self, evaluator=None):
         ev = evaluator or self.rolloutWorker
         r, s, c, ok = ev.evaluate(max(1, self.args.evaluate_task // self.env.n_envs))
+        self.rolloutWorker.stream_restart()  # the evaluation reset every chip: the training episodes in flight are gone
         self.episode_rewards.append(r); self.episode_steps.append(s)
         self.episode_constraints.append(c); self.success_rate.append(ok)
 
     def _save_model(self, k=None):
+        self.agents.policy.check_td_inputs()  # on EVERY rank: a rank that raised alone would leave the others in a collective
         if self.rank == 0:
             self.agents.policy.save_model(k)
         self.saves.append((self.time_steps, k))

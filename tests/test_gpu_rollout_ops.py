@@ -161,15 +161,17 @@ def test_compact_alive_lists_live_chips_in_order():
         assert torch.equal(lst[:k], want) and bool((lst[k:] == -7).all())
 
 
-def test_live_row_kernels_match_the_full_ones():
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 10])
+def test_live_row_kernels_match_the_full_ones(n):
     """crnn_front9_forward_live / rollout_gru_head_select_live (the rollout's kernels for the chips still playing) against the
-    full-batch kernels: same values, compact x rows, finished chips untouched."""
+    full-batch kernels: same values, compact x rows, finished chips untouched.  n = 1: one row per chip, where the kernel's
+    multiply-high row / rows_per_chip must degenerate to the identity."""
     import types
     from marl_dmfb_amd import _lib
     from marl_dmfb_amd.network.base_net import CRNN
     lib = _lib.rollout_ops()
     vp = C.c_void_p
-    E, n, A, H, T, t = 203, 4, 5, 128, 7, 3
+    E, A, H, T, t = 203, 5, 128, 7, 3
     torch.manual_seed(4)
     net = CRNN(types.SimpleNamespace(obs_shape=(3, 9, 9, 2, 245), hyper_hidden_dim=24, rnn_hidden_dim=H, n_actions=A, fov=9)).cuda()
     g = torch.Generator(device='cuda').manual_seed(1)

@@ -60,6 +60,7 @@ def main():
                      model_dir=os.path.join(a.out, 'model'), load_model=bool(a.load), load_model_name='0_', **info)
     if a.load:
         args.model_dir = a.load
+        args.load_model_name = '0_'
     tr = Trainer(env, args)
     emit(what='config', width=W, drop_num=n, n_envs=E, od=args.hyper_hidden_dim, train_time=a.train_time, batch_size=a.batch_size,
          buffer=args.buffer_size, anneal_steps=args.anneal_steps, lr=args.lr, target_update_cycle=args.target_update_cycle,
