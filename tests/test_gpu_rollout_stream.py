@@ -27,9 +27,10 @@ def _make(W, n, E, seed, buffer_size, trained=False, b_degrade=False, **over):
     from marl_dmfb_amd.env.dmfb import VecDMFB
     kw = dict(b_degrade=True, per_degrade=1.0) if b_degrade else {}
     env = VecDMFB(W, W, n, fov=9, n_envs=E, seed=seed, device='cuda:0', **kw)
-    args = make_args(drop_num=n, width=W, length=W, fov=9, device='cuda:0', n_envs=E, buffer_size=buffer_size,
+    args = make_args(drop_num=n if n in (2, 3, 4, 5, 10) else 2, width=W, length=W, fov=9, device='cuda:0', n_envs=E, buffer_size=buffer_size,
                      load_model=trained, load_model_name='0_', model_dir=CKPT, **env.get_env_info())
     args.__dict__.update(over)
+    args.drop_num = n
     torch.manual_seed(seed)
     agents = Agents(args)
     worker = RolloutWorker(env, agents, args)
@@ -81,10 +82,10 @@ def _oracle_episodes(cfg, E, seed, steps, T, n, O, A=5):
     return closed
 
 
-@pytest.mark.parametrize('case', ['random_4d', 'trained_10d', 'trained_10d_degrade'])
+@pytest.mark.parametrize('case', ['random_1d', 'trained_10d', 'trained_10d_degrade'])
 def test_stream_episodes_replay_through_the_oracle(case):
-    if case == 'random_4d':      # uniform random play on a small chip: most episodes time out, a few end early
-        W, n, E, K, trained, eps, deg = 9, 2, 40, 150, False, 1.0, False
+    if case == 'random_1d':      # uniform random play of ONE droplet on a small chip (a 245-byte row: the byte path of the close
+        W, n, E, K, trained, eps, deg = 9, 1, 40, 150, False, 1.0, False     # kernel): most episodes time out, some end early
     else:                        # the 20x20 / 10-droplet policy of profiles/r04/degre (73 % success): lengths 10..80
         W, n, E, K, trained, eps, deg = 20, 10, 24, 170, True, 0.05, case.endswith('degrade')
     seed = 11
@@ -103,7 +104,7 @@ def test_stream_episodes_replay_through_the_oracle(case):
     want = _oracle_episodes(cfg, E, seed, steps, T, n, O)
     assert len(want) == buf.host_closed == buf.current_size == acc[0] > E
     lens = np.array([d['len'] for d in want])
-    assert (lens < T).sum() >= 5 and len(set(lens.tolist())) >= 4, lens     # the case does exercise early ends
+    assert (lens < T).sum() >= 3 and len(set(lens.tolist())) >= 3, lens     # the case does exercise early ends
     np.testing.assert_array_equal(buf.host_len[:len(want)], lens)
     got = {k: buf.buffers[k][:len(want)].cpu().numpy() for k in KEYS}
     stats = buf.ring_stats[:len(want)].cpu().numpy()
