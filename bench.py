@@ -67,6 +67,8 @@ def parse(argv=None):
     ap.add_argument('--batch_size', type=int, default=512, help='episodes per learn')
     ap.add_argument('--train_time', type=int, default=4, help='learns per round')
     ap.add_argument('--buffer_size', type=int, default=16384, help='episodes kept in the HBM replay buffer')
+    ap.add_argument('--no_stream', dest='stream', action='store_false', default=None,
+                    help='one episode per chip per round (finished chips idle) instead of the continuous rollout')
     ap.add_argument('--no_graph', dest='graph', action='store_false',
                     help='play the rollout eagerly instead of replaying it as a captured HIP graph (the default)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
@@ -181,6 +183,8 @@ def loop_breakdown(trainer, rounds):
     """env+policy tier (rollouts only, no learn) and the per-phase times of a round, each phase bracketed by a
     device synchronisation.  Runs after the timed region, on the same trainer."""
     a = trainer.args
+    if trainer.stream:
+        return loop_breakdown_stream(trainer, rounds)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     played = 0
@@ -208,6 +212,41 @@ def loop_breakdown(trainer, rounds):
             'store_ms': round(t_store / rounds * 1e3, 3),
             'learn_ms': round(t_learn / rounds * 1e3, 3),
             'learn_ms_what': '%d learns x %d episodes (sample + forward + backward + clip + Adam)' % (a.train_time, a.batch_size)}
+
+
+def loop_breakdown_stream(trainer, rounds):
+    """The same for the continuous rollout: a round = episode_limit lock-steps of every chip (episodes go into the ring on the
+    device as they end, so there is no store phase), then the learns on host-drawn episodes."""
+    a, w, buf = trainer.args, trainer.rolloutWorker, trainer.buffer
+    K = int(getattr(a, 'round_steps', None) or a.episode_limit)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    played = closed = 0
+    for _ in range(rounds):
+        c, _, _, p = buf.sync_host(w.generate_steps(buf, K))
+        played += p
+        closed += c
+    torch.cuda.synchronize()
+    t_roll = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        for _ in range(a.train_time):
+            idx, lens = buf.draw(min(buf.current_size, a.batch_size))
+            if trainer._packed:
+                trainer.agents.policy.learn_packed(buf.buffers, idx, lens, trainer.trained_times)
+            else:
+                trainer.agents.train(buf.gather(idx), trainer.trained_times, max_len=int(lens[0]))
+            trainer.trained_times += 1
+    torch.cuda.synchronize()
+    t_learn = time.perf_counter() - t0
+    return {'env_policy': {'what': 'rollouts only (continuous: %d lock-steps of every chip per round, finished episodes written into the '
+                                   'replay ring on the device): Q-net forward + epsilon-greedy + env transition + reset of ended chips, no learn' % K,
+                           'rounds': rounds, 'env_steps_per_s': round(played / t_roll, 1), 'rollout_ms': round(t_roll / rounds * 1e3, 3),
+                           'episodes_closed_per_round': round(closed / rounds, 1)},
+            'store_ms': 0.0,
+            'learn_ms': round(t_learn / rounds * 1e3, 3),
+            'learn_ms_what': '%d learns x %d episodes (host draw + gather + forward + backward + clip + Adam), each over its batch\'s '
+                             'longest episode' % (a.train_time, a.batch_size)}
 
 
 def in_loop_step_kernel(trainer, env, n, fov):
@@ -249,7 +288,7 @@ def trained_policy_tier(cfg, a, device, rounds):
     env = VecDMFB(n_envs=E, seed=7, device=device, **cfg)
     info = env.get_env_info()
     args = make_args(device=str(device), n_envs=E, batch_size=256, train_time=4, buffer_size=8 * E,
-                     anneal_steps=E * info['episode_limit'] * rounds * 0.6, use_graph=a.graph, **info)
+                     anneal_steps=E * info['episode_limit'] * rounds * 0.6, use_graph=a.graph, stream=a.stream, **info)
     torch.manual_seed(0)
     tr = Trainer(env, args)
     torch.cuda.synchronize()
@@ -261,6 +300,40 @@ def trained_policy_tier(cfg, a, device, rounds):
     w = tr.rolloutWorker
     out = {'trained_rounds': rounds, 'train_seconds': round(t_train, 2), 'epsilon': round(float(w.epsilon), 4),
            'what': 'rollouts only (epsilon-greedy at the trained epsilon, episodes recorded), policy trained for %d rounds of %d chips' % (rounds, E)}
+    # the FULL loop (rollout + learns at the headline's cadence) under this policy: the figure to hold against the random-init
+    # headline (whose episodes all last episode_limit steps)
+    tr.args.batch_size, tr.args.train_time = a.batch_size, a.train_time
+    for _ in range(3):
+        tr.collect_and_learn()
+    torch.cuda.synchronize()
+    reps_l = 12
+    t0 = time.perf_counter()
+    played_l = closed_l = succ_l = 0
+    for _ in range(reps_l):
+        played_l += tr.collect_and_learn()
+        closed_l += tr.last_round.get('episodes', E)
+        succ_l += tr.last_round.get('success', 0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out['env_policy_learn'] = {
+        'env_steps_per_s': round(played_l / dt, 1), 'ms_per_round': round(dt / reps_l * 1e3, 3), 'env_steps_per_round': round(played_l / reps_l, 1),
+        'episodes_per_round': round(closed_l / reps_l, 1), 'mean_steps_per_episode': round(played_l / max(1, closed_l), 2),
+        'success_rate': round(succ_l / max(1, closed_l), 3), 'continuous_rollout': bool(tr.stream),
+        'what': 'full loop under the trained policy: %s + %d learns x %d episodes per round, %d rounds timed' % (
+            ('%d lock-steps of every chip' % info['episode_limit']) if tr.stream else 'one episode per chip', a.train_time, a.batch_size, reps_l)}
+    if tr.stream:
+        buf = tr.buffer
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        p_s = c_s = 0
+        for _ in range(reps_l):
+            c, _, _, p = buf.sync_host(w.generate_steps(buf, info['episode_limit']))
+            p_s += p
+            c_s += c
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out['continuous_rollout'] = {'env_steps_per_s': round(p_s / dt, 1), 'rollout_ms': round(dt / reps_l * 1e3, 3),
+                                     'episodes_per_round': round(c_s / reps_l, 1), 'what': 'rollouts only, every chip playing all the time'}
     w.live_threshold = 2.0   # this tier measures both forms whatever the live share (the default switches at 0.75)
     forms = (('skipping_finished_chips', w.compact_every or 4), ('all_rows_every_step', 0))
     reps = 6
@@ -592,7 +665,7 @@ def main(argv=None):
         env = VecDMFB(n_envs=a.n_envs, seed=1234, env_id0=rank * a.n_envs, device=device, **cfg)
     args = make_args(name=a.env, drop_num=a.drop_num, width=a.width, length=a.length, fov=a.fov, device=str(device), dist=dist,
                      n_envs=a.n_envs, batch_size=a.batch_size, train_time=a.train_time, buffer_size=a.buffer_size,
-                     use_graph=a.graph, force_dist=force_dist,
+                     use_graph=a.graph, force_dist=force_dist, stream=a.stream,
                      **env.get_env_info())
     torch.manual_seed(1234 + rank)
     trainer = Trainer(env, args)
@@ -659,6 +732,9 @@ def main(argv=None):
             what, a.width, a.length, n, fov, a.n_envs,
             ' (BASELINE configs[1])' if (a.env, a.degrade, a.width, a.length, n, fov, a.n_envs) == ('dmfb', False, 10, 10, 4, 9, 4096) else ''),
             'round': ('one GREEDY evaluation episode per chip (<=%d lock-steps), no learn' % env.max_step) if a.eval_only else
+                     ('continuous rollout: %d lock-steps of every chip (a chip whose episode ends starts the next one at once; episodes '
+                      'close into the replay ring on the device) + %d learns x %d episodes' % (env.max_step, a.train_time, a.batch_size))
+                     if trainer.stream else
                      'one episode per chip (<=%d lock-steps) + %d learns x %d episodes' % (env.max_step, a.train_time, a.batch_size),
             'parallelism': 'dp%d: chips sharded per rank, one flat RCCL all-reduce per learn' % world,
             'env_steps_per_round': round(played_all / a.steps, 1)},

@@ -109,6 +109,21 @@ int64_t gru_seq_row_blocks(int64_t R);
 int gru_seq_backward(const float *d_grad_hs, const float *d_gates, const float *d_hs, const float *d_h0, const float *d_w_hh,
                      int T, int64_t R, int hidden, float *d_d_igates, float *d_d_hgates, float *d_d_h0, float *d_bias_part,
                      void *stream);
+/* The same two for PACKED sequences of different lengths (VDN.learn on episodes that ended early: the reference trims a batch
+ * to its longest episode, agent/agent.py:51-61, and masks the padded steps, policy/vdn.py:115-122; here the padded steps are
+ * not computed at all).  The R rows are sorted by sequence length, longest first; step_rows (HOST array int32[T], non-increasing,
+ * step_rows[0] <= R) = rows still running at step t, i.e. the first step_rows[t] rows of the batch.  Every per-step tensor
+ * (d_igates, d_hs, d_gates, d_grad_hs, d_d_igates, d_d_hgates) holds the running rows of step 0, then those of step 1, ...
+ * back to back: sum(step_rows) rows in all, row (t, r) at offset sum(step_rows[0..t)) + r.  Rows not running at a step are
+ * neither read nor written; a sequence's gradient chain starts at its own last step.  T <= GRU_SEQ_MAX_STEPS.
+ * d_h_prev (backward, optional) float32[sum(step_rows)][H] receives h_{t-1} of every running (t, row) in that same layout, so that
+ * dW_hh = d_d_hgates^T @ d_h_prev is one GEMM although consecutive steps hold different numbers of rows. */
+#define GRU_SEQ_MAX_STEPS 255
+int gru_seq_forward_packed(const float *d_igates, const float *d_h0, const float *d_w_hh, const float *d_b_ih, const float *d_b_hh,
+                           int T, int64_t R, int hidden, const int32_t *step_rows, float *d_hs, float *d_gates, void *stream);
+int gru_seq_backward_packed(const float *d_grad_hs, const float *d_gates, const float *d_hs, const float *d_h0, const float *d_w_hh,
+                            int T, int64_t R, int hidden, const int32_t *step_rows, float *d_d_igates, float *d_d_hgates,
+                            float *d_d_h0, float *d_bias_part, float *d_h_prev, void *stream);
 int gru_last_hip_error(void);
 
 #ifdef __cplusplus

@@ -44,6 +44,20 @@ int vdn_td_forward(const float *d_q_eval, const float *d_q_target, const int8_t 
 int vdn_td_backward(const float *d_mtd, const float *d_mask, const int8_t *d_u, const float *d_grad_num, int32_t B, int32_t T,
                     int32_t t_limit, int32_t n_agents, int32_t n_actions, float *d_grad_q, void *stream);
 
+/* The same block for a batch whose padded steps were left out (episodes sorted by length, the valid (episode, step) UNITS of
+ * step 0 first, then those of step 1, ...: the layout of gru_seq_forward_packed in crnn_ops.h).  d_units int32[n_units]:
+ * unit j is the step `slot * t_limit + t` of the replay tensors, which are indexed directly (no gathered copies):
+ * d_u int8[slots*t_limit][n], d_r float32[slots*t_limit], d_avail_next int8[slots*t_limit][n][A], d_terminated / d_padded
+ * uint8[slots*t_limit].  Rows j*n .. j*n+n-1 of d_q_eval / d_q_target (float32[n_units*n][A]) belong to unit j.
+ * d_mtd / d_mask float32[n_units]; arithmetic and error behaviour as vdn_td_forward. */
+int vdn_td_forward_packed(const float *d_q_eval, const float *d_q_target, const int32_t *d_units, int32_t n_units, const int8_t *d_u,
+                          const float *d_r, const int8_t *d_avail_next, const uint8_t *d_terminated, const uint8_t *d_padded,
+                          int32_t n_agents, int32_t n_actions, float gamma, float *d_mtd, float *d_mask, int32_t *d_bad_actions,
+                          void *stream);
+/* d_grad_q float32[n_units*n][A] = the gradient of vdn_td_backward in that layout (every element written). */
+int vdn_td_backward_packed(const float *d_mtd, const float *d_mask, const int32_t *d_units, int32_t n_units, const int8_t *d_u,
+                           const float *d_grad_num, int32_t n_agents, int32_t n_actions, float *d_grad_q, void *stream);
+
 /* The tail of VDN.learn (policy/vdn.py:125-127): torch.nn.utils.clip_grad_norm_(eval_parameters, max_norm) followed by
  * optimizer.step() of torch.optim.Adam(lr, betas) (policy/vdn.py:67-68), for up to VDN_MAX_TENSORS float32 parameter tensors,
  * in two launches instead of the ~11 of the foreach / fused torch path:

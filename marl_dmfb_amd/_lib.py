@@ -159,6 +159,9 @@ def crnn_ops():
     lib.crnn_last_hip_error.argtypes = []
     lib.gru_seq_forward.argtypes = [vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, vp, vp, vp]
     lib.gru_seq_backward.argtypes = [vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, vp, vp, vp, vp, vp]
+    ip = C.POINTER(C.c_int32)
+    lib.gru_seq_forward_packed.argtypes = [vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, ip, vp, vp, vp]
+    lib.gru_seq_backward_packed.argtypes = [vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, ip, vp, vp, vp, vp, vp, vp]
     lib.gru_seq_row_blocks.argtypes = [i64]
     lib.gru_seq_row_blocks.restype = i64
     lib.gru_last_hip_error.argtypes = []
@@ -209,6 +212,8 @@ def vdn_ops():
     vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
     lib.vdn_td_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]
     lib.vdn_td_backward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.vdn_td_forward_packed.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
+    lib.vdn_td_backward_packed.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp]
     pp, pl = C.POINTER(C.c_void_p), C.POINTER(C.c_int64)
     f64 = C.c_double
     lib.vdn_clip_adam_step.argtypes = [i32, pp, pp, pp, pp, pl, f32, f64, f64, f64, f64, f64, f64, vp, vp, vp]

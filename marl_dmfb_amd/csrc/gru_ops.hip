@@ -32,6 +32,14 @@ constexpr int KQ = 32;   // k-range per thread
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// Packed sequences (include/crnn_ops.h: gru_seq_forward_packed): the rows are sorted by sequence length, longest first; step t
+// holds only the rows whose sequence is at least t + 1 long, stored back to back: rows [off[t], off[t + 1]) of every per-step
+// tensor are rows 0 .. off[t + 1] - off[t] - 1 of the batch.  A kernel argument (scalar loads), no device buffer.
+struct SeqOff {
+    int32_t packed;
+    int32_t off[GRU_SEQ_MAX_STEPS + 1];
+};
+
 // The dot products run on TWO rows at a time: (row 2p, row 2p + 1) sit next to each other in LDS, so one weight (broadcast) times
 // such a pair is a v_pk_fma_f32 on a natural register pair -- half the instructions of the scalar chains, the same sums in the
 // same order per row.  Written as an explicit 2-vector fma (from scalar code the compiler formed no packed instruction here), with
@@ -43,7 +51,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(kBlock) void k_gru_seq_fwd(const float *__restrict__ igates, const float *__restrict__ h0,
                                                         const float *__restrict__ w_hh, const float *__restrict__ b_ih,
                                                         const float *__restrict__ b_hh, int T, long R,
-                                                        float *__restrict__ hs, float *__restrict__ gates) {
+                                                        float *__restrict__ hs, float *__restrict__ gates, const SeqOff so) {
     __shared__ __attribute__((aligned(16))) float s_h[RW / 2][H][2];   // h of rows (2p, 2p + 1), interleaved
     __shared__ __attribute__((aligned(16))) float s_part[4][RW][3][H];
     const int tid = threadIdx.x, q = tid / H, u = tid - q * H;
@@ -62,13 +70,19 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_fwd(const float *__restrict_
     __syncthreads();
     const int ra = 2 * q;  // this thread finishes rows ra and ra + 1
     for (int t = 0; t < T; ++t) {
+        // packed: rows still running at step t = the first rt rows of the batch; a workgroup is done once its first row is
+        // (lengths only shrink along the rows); row (t, r) of the per-step tensors is row base + r
+        const long rt = so.packed ? (long)(so.off[t + 1] - so.off[t]) : R;
+        if (row0 >= rt) break;  // uniform
+        const int rvt = (int)min((long)rv, rt - row0);
+        const size_t base = so.packed ? (size_t)so.off[t] : (size_t)t * R;
         // input gates of my two rows (independent of the recurrence: issued first, consumed after the reduction)
         float ig[2][3];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int rr = ra + s;
 #pragma unroll
-            for (int g = 0; g < 3; ++g) ig[s][g] = rr < rv ? igates[((size_t)t * R + row0 + rr) * 3 * H + g * H + u] : 0.0f;
+            for (int g = 0; g < 3; ++g) ig[s][g] = rr < rvt ? igates[(base + row0 + rr) * 3 * H + g * H + u] : 0.0f;
         }
         // partial h @ W_hh^T over my k-quarter, all RW rows, two rows per instruction
 #pragma unroll
@@ -97,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_fwd(const float *__restrict_
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int rr = ra + s;
-            if (rr < rv) {
+            if (rr < rvt) {
                 const float hr = s_part[0][rr][0][u] + s_part[1][rr][0][u] + s_part[2][rr][0][u] + s_part[3][rr][0][u];
                 const float hz = s_part[0][rr][1][u] + s_part[1][rr][1][u] + s_part[2][rr][1][u] + s_part[3][rr][1][u];
                 const float hn = s_part[0][rr][2][u] + s_part[1][rr][2][u] + s_part[2][rr][2][u] + s_part[3][rr][2][u] + bhn;
@@ -106,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_fwd(const float *__restrict_
                 const float ng = tanhf(ig[s][2] + bin + rg * hn);
                 const float hp = s_h[rr >> 1][u][rr & 1];
                 const float hnew = (1.0f - zg) * ng + zg * hp;
-                const size_t o = ((size_t)t * R + row0 + rr);
+                const size_t o = base + row0 + rr;
                 hs[o * H + u] = hnew;
                 if (gates) {
                     gates[o * 4 * H + u] = rg; gates[o * 4 * H + H + u] = zg; gates[o * 4 * H + 2 * H + u] = ng;
@@ -123,7 +137,8 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
                                                         const float *__restrict__ hs, const float *__restrict__ h0,
                                                         const float *__restrict__ w_hh, int T, long R,
                                                         float *__restrict__ d_ig, float *__restrict__ d_hg,
-                                                        float *__restrict__ d_h0, float *__restrict__ bias_part) {
+                                                        float *__restrict__ d_h0, float *__restrict__ bias_part, const SeqOff so,
+                                                        float *__restrict__ h_prev_out) {
     __shared__ __attribute__((aligned(16))) float s_dhg[RW / 2][3][H][2];  // gate gradients of rows (2p, 2p + 1), interleaved
     __shared__ __attribute__((aligned(16))) float s_part[4][RW][H];
     const int tid = threadIdx.x, q = tid / H, u = tid - q * H;
@@ -141,18 +156,24 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
     float gh[2] = {0.0f, 0.0f};  // dL/dh_t arriving from the future for my two (row, u) entries
     float bs_r = 0.0f, bs_z = 0.0f, bs_n = 0.0f, bs_hn = 0.0f;  // column sums of the gate gradients (bias gradients)
     for (int t = T - 1; t >= 0; --t) {
+        const long rt = so.packed ? (long)(so.off[t + 1] - so.off[t]) : R;   // rows running at step t (see k_gru_seq_fwd)
+        if (row0 >= rt) continue;  // uniform: none of this workgroup's sequences reaches step t
+        const int rvt = (int)min((long)rv, rt - row0);
+        const size_t base = so.packed ? (size_t)so.off[t] : (size_t)t * R;
+        const size_t base_prev = so.packed ? (size_t)so.off[t > 0 ? t - 1 : 0] : (size_t)(t > 0 ? t - 1 : 0) * R;
         float direct[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int rr = ra + s;
             float dpr = 0.0f, dpz = 0.0f, dpn = 0.0f, dhn = 0.0f;
             direct[s] = 0.0f;
-            if (rr < rv) {
-                const size_t o = ((size_t)t * R + row0 + rr);
+            if (rr < rvt) {
+                const size_t o = base + row0 + rr;
                 const float g = grad_hs[o * H + u] + gh[s];
                 const float rg = gates[o * 4 * H + u], zg = gates[o * 4 * H + H + u], ng = gates[o * 4 * H + 2 * H + u],
                             hn = gates[o * 4 * H + 3 * H + u];
-                const float hp = t > 0 ? hs[(o - R) * H + u] : h0[(row0 + rr) * H + u];
+                const float hp = t > 0 ? hs[(base_prev + row0 + rr) * H + u] : h0[(row0 + rr) * H + u];
+                if (h_prev_out) h_prev_out[o * H + u] = hp;  // h_{t-1} in the layout of d_hgates: dW_hh = d_hgates^T h_prev is ONE GEMM
                 const float dn = g * (1.0f - zg), dz = g * (hp - ng);
                 direct[s] = g * zg;
                 dpn = dn * (1.0f - ng * ng);
@@ -219,14 +240,61 @@ thread_local int g_last = 0;
 
 extern "C" {
 
-int gru_seq_forward(const float *d_igates, const float *d_h0, const float *d_w_hh, const float *d_b_ih, const float *d_b_hh,
-                    int T, int64_t R, int hidden, float *d_hs, float *d_gates, void *stream) {
+static int make_seq_off(const int32_t *step_rows, int T, int64_t R, SeqOff &so) {
+    so.packed = step_rows ? 1 : 0;
+    if (!step_rows) return CRNN_OK;
+    if (T > GRU_SEQ_MAX_STEPS) return CRNN_ERR_UNSUPPORTED;
+    long off = 0, prev = R;
+    for (int t = 0; t < T; ++t) {
+        if (step_rows[t] < 0 || step_rows[t] > prev) return CRNN_ERR_BAD_ARG;  // counts must not grow, none above R
+        so.off[t] = (int32_t)off;
+        off += step_rows[t];
+        prev = step_rows[t];
+        if (off > 0x7fffffffL) return CRNN_ERR_BAD_ARG;
+    }
+    so.off[T] = (int32_t)off;
+    return CRNN_OK;
+}
+
+static int seq_forward(const float *d_igates, const float *d_h0, const float *d_w_hh, const float *d_b_ih, const float *d_b_hh,
+                       int T, int64_t R, int hidden, const int32_t *step_rows, float *d_hs, float *d_gates, void *stream) {
     if (!d_igates || !d_h0 || !d_w_hh || !d_b_ih || !d_b_hh || !d_hs || T < 0 || R < 0) return CRNN_ERR_BAD_ARG;
     if (hidden != H) return CRNN_ERR_UNSUPPORTED;
     if (T == 0 || R == 0) return CRNN_OK;
+    SeqOff so;
+    const int rc = make_seq_off(step_rows, T, R, so);
+    if (rc != CRNN_OK) return rc;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_gru_seq_fwd, dim3((unsigned)((R + RW - 1) / RW)), dim3(kBlock), 0, (hipStream_t)stream, d_igates, d_h0, d_w_hh,
-                       d_b_ih, d_b_hh, T, (long)R, d_hs, d_gates);
+                       d_b_ih, d_b_hh, T, (long)R, d_hs, d_gates, so);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last = (int)e; return CRNN_ERR_HIP; }
+    return CRNN_OK;
+}
+
+int gru_seq_forward(const float *d_igates, const float *d_h0, const float *d_w_hh, const float *d_b_ih, const float *d_b_hh,
+                    int T, int64_t R, int hidden, float *d_hs, float *d_gates, void *stream) {
+    return seq_forward(d_igates, d_h0, d_w_hh, d_b_ih, d_b_hh, T, R, hidden, nullptr, d_hs, d_gates, stream);
+}
+
+int gru_seq_forward_packed(const float *d_igates, const float *d_h0, const float *d_w_hh, const float *d_b_ih, const float *d_b_hh,
+                           int T, int64_t R, int hidden, const int32_t *step_rows, float *d_hs, float *d_gates, void *stream) {
+    if (!step_rows) return CRNN_ERR_BAD_ARG;
+    return seq_forward(d_igates, d_h0, d_w_hh, d_b_ih, d_b_hh, T, R, hidden, step_rows, d_hs, d_gates, stream);
+}
+
+static int seq_backward(const float *d_grad_hs, const float *d_gates, const float *d_hs, const float *d_h0, const float *d_w_hh,
+                        int T, int64_t R, int hidden, const int32_t *step_rows, float *d_d_igates, float *d_d_hgates, float *d_d_h0,
+                        float *d_bias_part, void *stream, float *d_h_prev = nullptr) {
+    if (!d_grad_hs || !d_gates || !d_hs || !d_h0 || !d_w_hh || !d_d_igates || !d_d_hgates || T < 0 || R < 0) return CRNN_ERR_BAD_ARG;
+    if (hidden != H) return CRNN_ERR_UNSUPPORTED;
+    if (T == 0 || R == 0) return CRNN_OK;
+    SeqOff so;
+    const int rc = make_seq_off(step_rows, T, R, so);
+    if (rc != CRNN_OK) return rc;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_gru_seq_bwd, dim3((unsigned)((R + RW - 1) / RW)), dim3(kBlock), 0, (hipStream_t)stream, d_grad_hs, d_gates, d_hs,
+                       d_h0, d_w_hh, T, (long)R, d_d_igates, d_d_hgates, d_d_h0, d_bias_part, so, d_h_prev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last = (int)e; return CRNN_ERR_HIP; }
     return CRNN_OK;
@@ -235,15 +303,15 @@ int gru_seq_forward(const float *d_igates, const float *d_h0, const float *d_w_h
 int gru_seq_backward(const float *d_grad_hs, const float *d_gates, const float *d_hs, const float *d_h0, const float *d_w_hh,
                      int T, int64_t R, int hidden, float *d_d_igates, float *d_d_hgates, float *d_d_h0, float *d_bias_part,
                      void *stream) {
-    if (!d_grad_hs || !d_gates || !d_hs || !d_h0 || !d_w_hh || !d_d_igates || !d_d_hgates || T < 0 || R < 0) return CRNN_ERR_BAD_ARG;
-    if (hidden != H) return CRNN_ERR_UNSUPPORTED;
-    if (T == 0 || R == 0) return CRNN_OK;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(k_gru_seq_bwd, dim3((unsigned)((R + RW - 1) / RW)), dim3(kBlock), 0, (hipStream_t)stream, d_grad_hs, d_gates, d_hs,
-                       d_h0, d_w_hh, T, (long)R, d_d_igates, d_d_hgates, d_d_h0, d_bias_part);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { g_last = (int)e; return CRNN_ERR_HIP; }
-    return CRNN_OK;
+    return seq_backward(d_grad_hs, d_gates, d_hs, d_h0, d_w_hh, T, R, hidden, nullptr, d_d_igates, d_d_hgates, d_d_h0, d_bias_part, stream);
+}
+
+int gru_seq_backward_packed(const float *d_grad_hs, const float *d_gates, const float *d_hs, const float *d_h0, const float *d_w_hh,
+                            int T, int64_t R, int hidden, const int32_t *step_rows, float *d_d_igates, float *d_d_hgates,
+                            float *d_d_h0, float *d_bias_part, float *d_h_prev, void *stream) {
+    if (!step_rows) return CRNN_ERR_BAD_ARG;
+    return seq_backward(d_grad_hs, d_gates, d_hs, d_h0, d_w_hh, T, R, hidden, step_rows, d_d_igates, d_d_hgates, d_d_h0, d_bias_part, stream,
+                        d_h_prev);
 }
 
 int64_t gru_seq_row_blocks(int64_t R) { return (R + RW - 1) / RW; }

@@ -57,6 +57,51 @@ __global__ __launch_bounds__(256) void k_td_backward(const float *__restrict__ m
     for (int a = 0; a < A; ++a) gq[row * A + a] = (bad_a || a == a_taken) ? d : 0.0f;
 }
 
+// The same block on PACKED (episode, step) units (include/vdn_ops.h: vdn_td_forward_packed): unit j is step units[j] % t_limit of
+// the episode in slot units[j] / t_limit of the replay tensors; its n rows of the Q tensors are rows j*n .. j*n + n - 1.
+__global__ __launch_bounds__(256) void k_td_forward_packed(const float *__restrict__ qe, const float *__restrict__ qt, const int32_t *__restrict__ units,
+                                                           int U, const int8_t *__restrict__ u, const float *__restrict__ r,
+                                                           const int8_t *__restrict__ avail, const uint8_t *__restrict__ term,
+                                                           const uint8_t *__restrict__ padded, int n, int A, float gamma,
+                                                           float *__restrict__ mtd, float *__restrict__ maskf, int32_t *__restrict__ bad) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= U) return;
+    const size_t ep = (size_t)units[j];
+    const size_t q0 = (size_t)j * n * A;
+    float qe_tot = 0.0f, qt_tot = 0.0f;
+    bool ok = true;
+    for (int i = 0; i < n; ++i) {
+        int a_taken = (int)u[ep * n + i];
+        if ((unsigned)a_taken >= (unsigned)A) { ok = false; a_taken = 0; }
+        qe_tot = qe_tot + qe[q0 + (size_t)i * A + a_taken];
+        float m = -3.4e38f;
+        for (int a = 0; a < A; ++a) {
+            const float v = avail[(ep * n + i) * A + a] == 0 ? -9999999.0f : qt[q0 + (size_t)i * A + a];
+            m = v > m ? v : m;
+        }
+        qt_tot = qt_tot + m;
+    }
+    const float not_term = 1.0f - (term[ep] ? 1.0f : 0.0f);
+    const float target = r[ep] + (gamma * qt_tot) * not_term;
+    const float mk = 1.0f - (padded[ep] ? 1.0f : 0.0f);
+    mtd[j] = ok ? mk * (target - qe_tot) : __builtin_nanf("");
+    maskf[j] = mk;
+    if (!ok && bad) atomicAdd(bad, 1);
+}
+
+__global__ __launch_bounds__(256) void k_td_backward_packed(const float *__restrict__ mtd, const float *__restrict__ maskf, const int32_t *__restrict__ units,
+                                                            const int8_t *__restrict__ u, const float *__restrict__ g, long rows, int n, int A,
+                                                            float *__restrict__ gq) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int i = (int)(row % n);
+    const long j = row / n;
+    const float d = -((2.0f * mtd[j]) * maskf[j]) * g[0];
+    const int a_taken = (int)u[(size_t)units[j] * n + i];
+    const bool bad_a = (unsigned)a_taken >= (unsigned)A;
+    for (int a = 0; a < A; ++a) gq[row * A + a] = (bad_a || a == a_taken) ? d : 0.0f;
+}
+
 }  // namespace
 
 namespace {
@@ -192,6 +237,37 @@ int vdn_td_backward(const float *d_mtd, const float *d_mask, const int8_t *d_u, 
     const long rows = (long)T * B * n_agents;
     hipLaunchKernelGGL(k_td_backward, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_mtd, d_mask, d_u,
                        d_grad_num, B, T, t_limit, n_agents, n_actions, d_grad_q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last = (int)e; return VDN_ERR_HIP; }
+    return VDN_OK;
+}
+
+int vdn_td_forward_packed(const float *d_q_eval, const float *d_q_target, const int32_t *d_units, int32_t n_units, const int8_t *d_u,
+                          const float *d_r, const int8_t *d_avail_next, const uint8_t *d_terminated, const uint8_t *d_padded,
+                          int32_t n_agents, int32_t n_actions, float gamma, float *d_mtd, float *d_mask, int32_t *d_bad_actions,
+                          void *stream) {
+    if (!d_q_eval || !d_q_target || !d_units || !d_u || !d_r || !d_avail_next || !d_terminated || !d_padded || !d_mtd || !d_mask ||
+        n_units < 0 || n_agents < 1 || n_actions < 1 || n_actions > 127)
+        return VDN_ERR_BAD_ARG;
+    if (n_units == 0) return VDN_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_td_forward_packed, dim3((unsigned)((n_units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_q_eval, d_q_target,
+                       d_units, n_units, d_u, d_r, d_avail_next, d_terminated, d_padded, n_agents, n_actions, gamma, d_mtd, d_mask,
+                       d_bad_actions);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last = (int)e; return VDN_ERR_HIP; }
+    return VDN_OK;
+}
+
+int vdn_td_backward_packed(const float *d_mtd, const float *d_mask, const int32_t *d_units, int32_t n_units, const int8_t *d_u,
+                           const float *d_grad_num, int32_t n_agents, int32_t n_actions, float *d_grad_q, void *stream) {
+    if (!d_mtd || !d_mask || !d_units || !d_u || !d_grad_num || !d_grad_q || n_units < 0 || n_agents < 1 || n_actions < 1 || n_actions > 127)
+        return VDN_ERR_BAD_ARG;
+    if (n_units == 0) return VDN_OK;
+    const long rows = (long)n_units * n_agents;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_td_backward_packed, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_mtd, d_mask, d_units,
+                       d_u, d_grad_num, rows, n_agents, n_actions, d_grad_q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last = (int)e; return VDN_ERR_HIP; }
     return VDN_OK;

@@ -335,6 +335,71 @@ class _GRUSeqHip(torch.autograd.Function):
         return d_ig, d_h0, d_w_hh, d_b[:3 * H], d_b[3 * H:]
 
 
+class _GRUSeqHipPacked(torch.autograd.Function):
+    """`_GRUSeqHip` for sequences of different lengths stored without their padded steps (include/crnn_ops.h:
+    gru_seq_forward_packed): rows sorted by length, step t holds the first step_rows[t] rows, steps back to back.  igates is
+    (V_pad, 3H) with V = sum(step_rows) real rows; rows V .. V_pad-1 (GEMM-friendly padding) are zero in every output."""
+
+    @staticmethod
+    def _steps(step_rows):
+        import ctypes as C
+        return (C.c_int32 * len(step_rows))(*[int(v) for v in step_rows])
+
+    @staticmethod
+    def run_forward(igates, h0, w_hh, b_ih, b_hh, step_rows, save):
+        import ctypes as C
+        lib = _GRUSeqHip._lib()
+        Vp, G = igates.shape
+        H, T, R, V = G // 3, len(step_rows), h0.shape[0], int(sum(step_rows))
+        igates, h0, w_hh = igates.contiguous(), h0.contiguous(), w_hh.contiguous()
+        hs = torch.empty((Vp, H), dtype=torch.float32, device=igates.device)
+        hs[V:].zero_()
+        gates = torch.empty((Vp, 4 * H), dtype=torch.float32, device=igates.device) if save else None
+        vp = C.c_void_p
+        rc = lib.gru_seq_forward_packed(vp(igates.data_ptr()), vp(h0.data_ptr()), vp(w_hh.data_ptr()), vp(b_ih.data_ptr()),
+                                        vp(b_hh.data_ptr()), T, R, H, _GRUSeqHipPacked._steps(step_rows), vp(hs.data_ptr()),
+                                        vp(gates.data_ptr()) if save else None,
+                                        vp(torch.cuda.current_stream(igates.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('gru_seq_forward_packed failed: %d (hip %d)' % (rc, lib.gru_last_hip_error()))
+        return hs, gates
+
+    @staticmethod
+    def forward(ctx, igates, h0, w_hh, b_ih, b_hh, step_rows):
+        hs, gates = _GRUSeqHipPacked.run_forward(igates.detach(), h0.detach(), w_hh.detach(), b_ih.detach(), b_hh.detach(), step_rows, True)
+        ctx.save_for_backward(hs, gates, h0, w_hh)
+        ctx.step_rows = list(step_rows)
+        return hs
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        import ctypes as C
+        hs, gates, h0, w_hh = ctx.saved_tensors
+        lib = _GRUSeqHip._lib()
+        step_rows = ctx.step_rows
+        Vp, H = hs.shape
+        T, R, V = len(step_rows), h0.shape[0], int(sum(step_rows))
+        grad_out = grad_out.contiguous()
+        h0c, w = h0.contiguous(), w_hh.contiguous()
+        d_ig = torch.empty((Vp, 3 * H), dtype=torch.float32, device=hs.device)
+        d_hg = torch.empty_like(d_ig)
+        h_prev = torch.empty((Vp, H), dtype=torch.float32, device=hs.device)
+        for t in (d_ig, d_hg, h_prev):
+            t[V:].zero_()
+        d_h0 = torch.zeros_like(h0c)
+        bias_part = torch.empty((lib.gru_seq_row_blocks(R), 6 * H), dtype=torch.float32, device=hs.device)
+        vp = C.c_void_p
+        rc = lib.gru_seq_backward_packed(vp(grad_out.data_ptr()), vp(gates.data_ptr()), vp(hs.data_ptr()), vp(h0c.data_ptr()),
+                                         vp(w.data_ptr()), T, R, H, _GRUSeqHipPacked._steps(step_rows), vp(d_ig.data_ptr()),
+                                         vp(d_hg.data_ptr()), vp(d_h0.data_ptr()), vp(bias_part.data_ptr()), vp(h_prev.data_ptr()),
+                                         vp(torch.cuda.current_stream(hs.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('gru_seq_backward_packed failed: %d (hip %d)' % (rc, lib.gru_last_hip_error()))
+        d_w_hh = _wgrad_splitk(d_hg, h_prev)   # sum over every running (t, row) of d_hgates^T h_{t-1}
+        d_b = bias_part.sum(0)
+        return d_ig, d_h0, d_w_hh, d_b[:3 * H], d_b[3 * H:], None
+
+
 def gru_sequence(igates, h0, w_hh, b_ih, b_hh, impl='hip'):
     """hs (T, R, H) of the GRU recurrence given the input-side pre-activations of all steps."""
     if impl == 'hip' and h0.shape[-1] == 128 and igates.dtype == torch.float32:
@@ -435,6 +500,20 @@ class CRNN(nn.Module):
                 hs.append(h)
         q = self.fc1(torch.stack(hs, dim=0).view(T * R, -1)).view(T, R, -1)
         return q, h
+
+    def recurrent_seq_packed(self, x, step_rows, R):
+        """`recurrent_seq` on PACKED rows (GPU): x (V_pad, F) holds, step after step, the GRU inputs of the rows still running
+        (`step_rows[t]` = the first so many of the R length-sorted rows); returns q (V_pad, A) in the same layout.  Zero initial
+        hidden state (policy/vdn.py:198-203)."""
+        w_ih = self.weight_ih_padded() if x.shape[-1] == self.padded_cols() != self.rnn.weight_ih.shape[1] else self.rnn.weight_ih
+        igates = _LinearSplitK.apply(x, w_ih, None)
+        h0 = torch.zeros((R, self.rnn_hidden_dim), dtype=torch.float32, device=x.device)
+        args = (igates, h0, self.rnn.weight_hh, self.rnn.bias_ih, self.rnn.bias_hh)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in args):
+            hs = _GRUSeqHipPacked.apply(*args, step_rows)
+        else:
+            hs = _GRUSeqHipPacked.run_forward(*args, step_rows, False)[0]
+        return _LinearSplitK.apply(hs, self.fc1.weight, self.fc1.bias)
 
     def forward(self, inputs, hidden_state):
         """Reference signature: inputs (R, obs+n_actions) float32, hidden (R, H) -> (q, h)."""

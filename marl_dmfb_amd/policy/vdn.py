@@ -88,6 +88,52 @@ class _TDLoss(torch.autograd.Function):
         return gq, None, None, None, None, None, None, None, None, None
 
 
+class _TDLossPacked(torch.autograd.Function):
+    """`_TDLoss` on packed (episode, step) units (include/vdn_ops.h: vdn_td_forward_packed): the Q tensors hold only the valid steps
+    of the length-sorted batch, the replay tensors are indexed in place through `units` (= slot * T + t)."""
+
+    @staticmethod
+    def forward(ctx, q_eval, q_target, units, n_units, u, r, avail_next, terminated, padded, n, A, gamma, bad=None):
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.vdn_ops()
+        vp = C.c_void_p
+        q_eval, q_target = q_eval.contiguous(), q_target.contiguous()
+        mtd = torch.empty(n_units, dtype=torch.float32, device=u.device)
+        mask = torch.empty(n_units, dtype=torch.float32, device=u.device)
+        rc = lib.vdn_td_forward_packed(vp(q_eval.data_ptr()), vp(q_target.data_ptr()), vp(units.data_ptr()), n_units, vp(u.data_ptr()),
+                                       vp(r.data_ptr()), vp(avail_next.data_ptr()), vp(terminated.data_ptr()), vp(padded.data_ptr()),
+                                       n, A, float(gamma), vp(mtd.data_ptr()), vp(mask.data_ptr()),
+                                       None if bad is None else vp(bad.data_ptr()), vp(torch.cuda.current_stream(u.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('vdn_td_forward_packed failed: %d (hip %d)' % (rc, lib.vdn_last_hip_error()))
+        ctx.save_for_backward(mtd, mask, units, u)
+        ctx.dims = (n_units, n, A, q_eval.shape[0])
+        num, mask_sum = (mtd * mtd).sum(), mask.sum()
+        ctx.mark_non_differentiable(mask_sum)
+        return num, mask_sum
+
+    @staticmethod
+    def backward(ctx, g_num, _g_mask):
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.vdn_ops()
+        vp = C.c_void_p
+        mtd, mask, units, u = ctx.saved_tensors
+        n_units, n, A, rows_pad = ctx.dims
+        gq = torch.empty((rows_pad, A), dtype=torch.float32, device=u.device)
+        gq[n_units * n:].zero_()
+        g = g_num.reshape(1).to(torch.float32).contiguous()
+        rc = lib.vdn_td_backward_packed(vp(mtd.data_ptr()), vp(mask.data_ptr()), vp(units.data_ptr()), n_units, vp(u.data_ptr()),
+                                        vp(g.data_ptr()), n, A, vp(gq.data_ptr()), vp(torch.cuda.current_stream(u.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('vdn_td_backward_packed failed: %d (hip %d)' % (rc, lib.vdn_last_hip_error()))
+        return (gq,) + (None,) * 12
+
+
+PACK_ROWS = 2048  # packed row counts are rounded up to a multiple of this (zero rows): few distinct GEMM shapes, split-K friendly
+
+
 class VDN:
     def __init__(self, args):
         self.args = args
@@ -286,6 +332,76 @@ class VDN:
             loss = num.detach() / total
         else:
             loss = (masked_td_error ** 2).sum() / mask.sum()
+            loss.backward()
+        return self._step_and_sync(loss, train_step)
+
+    def packed_ok(self, buffers):
+        """learn_packed applies to the replay ring on the GPU (int8 / float32 / bool episode tensors), the fov-9 CRNN with the HIP
+        front end and GRU sequence kernels, and the parameter-free VDN mixer."""
+        import ctypes  # noqa: F401
+        net = self.eval_rnn
+        o = buffers.get('o')
+        if not (isinstance(o, torch.Tensor) and o.is_cuda and o.dtype == torch.int8 and o.is_contiguous() and self.args.alg == 'vdn'
+                and self.args.last_action and hasattr(net, 'recurrent_seq_packed') and getattr(net, 'rnn_hidden_dim', 0) == 128
+                and len(list(self.eval_vdn_net.parameters())) == 0 and o.shape[1] <= 255):
+            return False
+        want = {'u': torch.int8, 'r': torch.float32, 'avail_u_next': torch.int8, 'terminated': torch.bool, 'padded': torch.bool,
+                'u_onehot': torch.int8, 'o_next': torch.int8}
+        if any(not (isinstance(buffers.get(k), torch.Tensor) and buffers[k].dtype == dt and buffers[k].is_contiguous()) for k, dt in want.items()):
+            return False
+        probe = o.view(-1, o.shape[-1])[:1]
+        with torch.no_grad():
+            return bool(hasattr(net, '_hip_conv_ok') and net._hip_conv_ok(probe) and net._hip_geometry() == 9)
+
+    def learn_packed(self, buffers, idx, lens, train_step):
+        """VDN.learn (policy/vdn.py:79-132) on the episodes in slots `idx` of the replay tensors `buffers`, WITHOUT their padded
+        steps.  idx / lens: host integer arrays sorted by episode length, longest first (ReplayBuffer.draw).  The reference trims
+        the batch to its longest episode (agent/agent.py:51-70) and multiplies the TD error of a padded step by 0
+        (policy/vdn.py:118-122); here those steps are never computed: the valid (episode, step) units are laid out step after step
+        (step t: the episodes longer than t), the conv front end, the GRU input projection and the head run on exactly those rows,
+        the GRU sequence kernels stop every row at its own length, and the TD block indexes the replay tensors in place."""
+        import numpy as np
+        dev, n, A = self.device, self.n_agents, self.n_actions
+        idx, lens = np.asarray(idx, np.int64), np.asarray(lens, np.int64)
+        B, T_ring, O = len(idx), buffers['o'].shape[1], buffers['o'].shape[-1]
+        Tm = int(lens[0])
+        counts = (lens[None, :] > np.arange(Tm)[:, None]).sum(1)            # episodes still running at step t (non-increasing)
+        units_np = np.concatenate([idx[:c] * T_ring + t for t, c in enumerate(counts)]).astype(np.int32)
+        U = int(units_np.shape[0])
+        V = U * n
+        Vp = -(-V // PACK_ROWS) * PACK_ROWS
+        units = torch.from_numpy(units_np).to(dev, non_blocking=True)
+        rows = (units.to(torch.int64)[:, None] * n + torch.arange(n, device=dev)[None]).reshape(-1)   # rows of the (slot, t, agent) tensors
+        o_rows, on_rows = buffers['o'].view(-1, O), buffers['o_next'].view(-1, O)
+        oh_rows = buffers['u_onehot'].view(-1, A)
+
+        def packed(src, sel, lo=0):
+            out = torch.empty((Vp, src.shape[1]), dtype=src.dtype, device=dev)
+            if lo:
+                out[:lo].zero_()
+            torch.index_select(src, 0, sel, out=out[lo:lo + sel.shape[0]])
+            out[lo + sel.shape[0]:].zero_()
+            return out
+        obs_e, obs_t, oh_t = packed(o_rows, rows), packed(on_rows, rows), packed(oh_rows, rows)
+        oh_e = packed(oh_rows, rows[B * n:] - n, lo=B * n)   # last action of step t = u_onehot[t - 1]; zeros at t == 0 (vdn.py:150-160)
+        x_e = self._features(self.eval_rnn, obs_e, oh_e)
+        with torch.no_grad():
+            x_t = self._features(self.target_rnn, obs_t, oh_t)
+        step_rows = [int(c) * n for c in counts]
+        q_e = self.eval_rnn.recurrent_seq_packed(x_e, step_rows, B * n)
+        with torch.no_grad():
+            q_t = self.target_rnn.recurrent_seq_packed(x_t, step_rows, B * n)
+        if self._td_bad is None:
+            self._td_bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        num, mask_sum = _TDLossPacked.apply(q_e, q_t, units, U, buffers['u'], buffers['r'], buffers['avail_u_next'],
+                                            buffers['terminated'], buffers['padded'], n, A, self.args.gamma, self._td_bad)
+        self.optimizer.zero_grad()
+        if self.dist:
+            num.backward()
+            total = self._allreduce_grads(mask_sum)
+            loss = num.detach() / total
+        else:
+            loss = num / mask_sum
             loss.backward()
         return self._step_and_sync(loss, train_step)
 

@@ -49,6 +49,7 @@ class Trainer:
         stream = getattr(args, 'stream', None)
         self.stream = bool(self.rolloutWorker.use_graph and self.rolloutWorker.stream_ok()) if stream is None else bool(stream)
         self.last_round = {}
+        self._packed = None  # continuous mode: VDN.learn_packed applies (decided at the first learn)
         self.dist = bool(self.agents.policy.dist)
         self.rank = torch.distributed.get_rank() if self.dist else 0
         self.saves = []  # (time_steps, evaluate index or None) of every checkpoint written, for tests/logs
@@ -72,8 +73,14 @@ class Trainer:
         k_batch = min(self.buffer.current_size, self.args.batch_size)
         draws = [self.buffer.draw(k_batch) for _ in range(learns)]   # host RNG: the order of the draws is fixed here
         prefetched = []
+        if self._packed is None:
+            self._packed = bool(getattr(self.args, 'packed_learn', True) and hasattr(pol, 'packed_ok') and pol.packed_ok(self.buffer.buffers))
         for k in range(learns):
             idx, lens = draws[k]
+            if self._packed:   # the padded steps of the drawn episodes are never computed; the ring is read in place
+                pol.learn_packed(self.buffer.buffers, idx, lens, self.trained_times)
+                self.trained_times += 1
+                continue
             mini_batch = prefetched.pop() if prefetched else self.buffer.gather(idx)
             if self.dist and k + 1 < learns and getattr(self.args, 'prefetch_sample', True):
                 nxt = draws[k + 1][0]

@@ -41,6 +41,15 @@ def test_learn_with_host_length_bound_matches_reference_gpu(path):
     learn_golden_check(path, 'cuda:0', rtol=1e-5, atol=1e-5, replay_dtypes=True, host_len_bound=True)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', [f for f in FILES if 'meda' not in os.path.basename(f)], ids=os.path.basename)
+def test_learn_packed_matches_reference_gpu(path):
+    """VDN.learn_packed (what Trainer runs in continuous mode): conv front end, GRU input projection and head on the valid
+    (episode, step) rows only, GRU sequence kernels that stop every row at its own length, TD block indexing the replay tensors
+    in place -- against the reference's numbers for batches whose episodes have 3 .. 80 valid steps."""
+    learn_golden_check(path, 'cuda:0', rtol=1e-5, atol=1e-5, replay_dtypes=True, packed=True)
+
+
 @pytest.mark.parametrize('path', FILES, ids=os.path.basename)
 def test_learn_with_host_length_bound_matches_reference_cpu(path):
     learn_golden_check(path, 'cpu', rtol=1e-5, atol=1e-5, host_len_bound=True)

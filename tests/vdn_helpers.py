@@ -12,14 +12,16 @@ def det_init(module, salt=0.0):
             p.copy_((scale * torch.sin(0.37 * i + 1.7 * k + salt)).to(torch.float32).view_as(p))
 
 
-def learn_golden_check(path, device, rtol, atol, replay_dtypes=False, host_len_bound=False):
+def learn_golden_check(path, device, rtol, atol, replay_dtypes=False, host_len_bound=False, packed=False):
     """replay_dtypes: hand the batch over exactly as ReplayBuffer.sample does on the GPU (r float32, int8 actions, bool flags) and
     REQUIRE the shipped learn path (fused TD block + time-major Q values, policy/vdn.py:_td_fused_ok); otherwise the golden's own
     dtypes (r float64), which take the tensor-op TD block.
     host_len_bound: Agents.train(..., max_len=episode_limit) -- what Trainer.collect_and_learn does by default (the longest episode
     ever stored, handed over from the host): the learn runs over every slot of the batch although the reference trims it to the
     batch's own longest episode (agent/agent.py:51-70); the extra steps are padded in every episode, so the reference's numbers
-    must come out all the same."""
+    must come out all the same.
+    packed: VDN.learn_packed -- the golden batch stands in for the replay ring (one slot per episode), the episodes are handed over
+    as (slot indices, lengths) sorted by length like ReplayBuffer.draw does, and the padded steps are never computed."""
     from marl_dmfb_amd.agent.agent import Agents
     from marl_dmfb_amd.common.arguments import make_args
     g = np.load(path)
@@ -51,7 +53,12 @@ def learn_golden_check(path, device, rtol, atol, replay_dtypes=False, host_len_b
             assert agents.policy._td_fused_ok(batch), 'the shipped (fused TD) learn path must be the one under test'
         else:
             assert not agents.policy._td_fused_ok(batch)
-        if host_len_bound:
+        if packed:
+            assert agents.policy.packed_ok(batch), 'the packed learn path must apply to this golden'
+            lens = (~batch['padded'][:, :, 0]).sum(1).cpu().numpy()
+            order = np.argsort(-lens, kind='stable')
+            agents.policy.learn_packed(batch, order, lens[order], step)
+        elif host_len_bound:
             agents.train(batch, step, max_len=batch['o'].shape[1])
         else:
             agents.train(batch, step)
