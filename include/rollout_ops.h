@@ -96,7 +96,8 @@ int rollout_post_step(int32_t n_envs, int32_t episode_limit, int32_t t, uint8_t 
  *   d_ep_acc float64[E][3]    running (reward, constraints, success) of the episode (rollout.py:122-124)
  *   d_chip_acc int64[E][4]    += (episodes closed, their steps with the failure inflation of rollout.py:148-149, successes,
  *                                 env steps played); the caller sums / clears them between rounds
- *   d_close_slot int32[E]     written by rollout_stream_post: ring slot the chip's episode closes into this lock-step, or -1
+ *   d_close_slot int32[E]     written by rollout_stream_step: ring slot the chip's episode closed into in this lock-step, or -1
+ *   d_state_alt int64[4]      the second buffer of the ring state (see rollout_stream_step)
  * rollout_ring: the replay buffer's tensors (common/replay_buffer.py:10-28, `slots` episodes of T steps) plus
  *   d_len int32[slots]        valid steps of the episode in each slot (0 = never written)
  *   d_stats float64[slots][4] (reward, steps incl. failure inflation, constraints, success) = generate_episode's return values
@@ -109,6 +110,7 @@ typedef struct {
     double *d_ep_acc;
     int64_t *d_chip_acc;
     int32_t *d_close_slot;
+    int64_t *d_state_alt;
 } rollout_stage;
 
 typedef struct {
@@ -130,26 +132,26 @@ int rollout_gru_head_select_stream(const float *d_igates, const float *d_hgates,
                                    int32_t episode_limit, const int32_t *d_t_ep, float *d_q, void *stream);
 
 /* After the transition of a lock-step (rollout.py:118-129), for every chip e at step t = d_t_ep[e] of its episode:
- *   stage r[e][t] = team_reward[e]; the episode's running sums += this step's reward / constraints / success;
- *   if d_term[e]: the episode closes into ring slot (cursor + k) % slots, k = rank of e among the chips closing in this lock-step
- *   in ASCENDING chip order (deterministic); ring d_len / d_stats of the slot and the chip's counters are written, the running
- *   sums cleared; d_close_slot[e] = that slot, else -1.  Then ring cursor / size / total advance, *d_epsilon = max(*d_epsilon -
- *   anneal * n_envs, min_epsilon) (every chip played a step; epsilon_anneal_scale == 'step', rollout.py:126-127), *d_draw += 1.
- * d_t_ep is NOT advanced here (rollout_stream_close does that). */
-int rollout_stream_post(int32_t n_envs, int32_t episode_limit, const rollout_ring *ring, const uint8_t *d_term,
+ *   stage r[e][t] = team_reward[e], o_next[e][t] = d_obs_new[e] (and o0[e] = d_obs_prev[e] when t == 0: the observation the step
+ *   was chosen from); the episode's running sums += this step's reward / constraints / success;
+ *   if d_term[e]: the episode closes into ring slot (cursor + k) % slots, k = number of LOWER-numbered chips closing in this
+ *   lock-step (deterministic, chip order): the whole episode is written into the slot with the reference's padding
+ *   (rollout.py:131-141: rows behind the end are zeros, padded = 1, terminated = 1, avail_u = avail_u_next = 0; o[t] = o0 for
+ *   t == 0, o_next[t - 1] after), ring d_len / d_stats of the slot and the chip's counters are written, the running sums, the
+ *   chip's rows of d_hidden (float32[E*n][hidden]; policy.init_hidden, rollout.py:112) and d_last_onehot (rollout.py:110) are
+ *   cleared, d_close_slot[e] = that slot and d_t_ep[e] = 0; every other chip gets d_close_slot[e] = -1 and d_t_ep[e] += 1.
+ *   Then ring cursor / size / total advance, *d_epsilon = max(*d_epsilon - anneal * n_envs, min_epsilon) (every chip played a
+ *   step; epsilon_anneal_scale == 'step', rollout.py:126-127), *d_draw += 1.
+ * The ring state is double-buffered inside one call (the cursor is read by every closing chip while the new one is published):
+ * parity 0 reads ring->d_state and writes stage->d_state_alt, parity 1 the other way round; the caller alternates and, after an odd
+ * number of calls, copies d_state_alt back.  The caller then resets the closed chips' env (dmfb_vec_reset / meda_vec_reset with
+ * d_term as mask), which also rewrites their rows of d_obs_new with the first observation of the next episode.
+ * obs_row_bytes = n_agents * observation bytes. */
+int rollout_stream_step(int32_t n_envs, int32_t n_agents, int32_t n_actions, int32_t episode_limit, int32_t obs_row_bytes,
+                        int32_t hidden, const int8_t *d_obs_prev, const int8_t *d_obs_new, const uint8_t *d_term,
                         const double *d_team_reward, const void *d_constraints, int32_t constraints_f64, const uint8_t *d_success,
-                        const rollout_stage *stage, float *d_epsilon, float anneal, float min_epsilon, uint32_t *d_draw, void *stream);
-
-/* Then, per chip: o_next[e][t] = d_obs_new[e] is staged (and o0[e] = d_obs_prev[e] when t == 0: the observation the step was
- * chosen from); a chip with d_close_slot[e] >= 0 writes its whole episode into that ring slot with the reference's padding
- * (rollout.py:131-141: rows behind the end are zeros, padded = 1, terminated = 1, avail_u = avail_u_next = 0; o[t] = o0 for
- * t == 0, o_next[t - 1] after), clears its rows of d_hidden (float32[E*n][hidden]; policy.init_hidden, rollout.py:112) and
- * d_last_onehot (rollout.py:110) and sets d_t_ep[e] = 0; every other chip advances d_t_ep[e] by one.  The caller then resets the
- * closed chips' env (dmfb_vec_reset / meda_vec_reset with d_term as mask), which also rewrites their rows of d_obs_new with the
- * first observation of the next episode.  obs_row_bytes = n_agents * observation bytes. */
-int rollout_stream_close(int32_t n_envs, int32_t n_agents, int32_t n_actions, int32_t episode_limit, int32_t obs_row_bytes,
-                         int32_t hidden, const int8_t *d_obs_prev, const int8_t *d_obs_new, const rollout_stage *stage,
-                         const rollout_ring *ring, float *d_hidden, int8_t *d_last_onehot, void *stream);
+                        const rollout_stage *stage, const rollout_ring *ring, int32_t parity, float *d_hidden, int8_t *d_last_onehot,
+                        float *d_epsilon, float anneal, float min_epsilon, uint32_t *d_draw, void *stream);
 
 int rollout_last_hip_error(void);
 

@@ -58,6 +58,12 @@ int vdn_td_forward_packed(const float *d_q_eval, const float *d_q_target, const 
 int vdn_td_backward_packed(const float *d_mtd, const float *d_mask, const int32_t *d_units, int32_t n_units, const int8_t *d_u,
                            const float *d_grad_num, int32_t n_agents, int32_t n_actions, float *d_grad_q, void *stream);
 
+/* The inputs of the packed learn (policy/vdn.py:134-165: o / o_next of a step and the previous step's action one-hot) copied out
+ * of the replay tensors unit by unit: d_dst unit j (unit_bytes bytes) = d_src unit d_units[j] + unit_shift, or zeros for
+ * j < zero_below (the last action of step 0).  A unit = the n_agents consecutive rows of one (slot, step). */
+int vdn_gather_units(const void *d_src, int32_t unit_bytes, const int32_t *d_units, int32_t n_units, int32_t unit_shift,
+                     int32_t zero_below, void *d_dst, void *stream);
+
 /* The tail of VDN.learn (policy/vdn.py:125-127): torch.nn.utils.clip_grad_norm_(eval_parameters, max_norm) followed by
  * optimizer.step() of torch.optim.Adam(lr, betas) (policy/vdn.py:67-68), for up to VDN_MAX_TENSORS float32 parameter tensors,
  * in two launches instead of the ~11 of the foreach / fused torch path:

@@ -173,7 +173,7 @@ class RolloutStage(C.Structure):
     """include/rollout_ops.h: rollout_stage"""
     _fields_ = [('d_t_ep', C.c_void_p), ('d_o0', C.c_void_p), ('d_o_next', C.c_void_p), ('d_u', C.c_void_p),
                 ('d_onehot', C.c_void_p), ('d_r', C.c_void_p), ('d_ep_acc', C.c_void_p), ('d_chip_acc', C.c_void_p),
-                ('d_close_slot', C.c_void_p)]
+                ('d_close_slot', C.c_void_p), ('d_state_alt', C.c_void_p)]
 
 
 class RolloutRing(C.Structure):
@@ -197,8 +197,7 @@ def rollout_ops():
     lib.rollout_post_step.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp]
     lib.rollout_gru_head_select_stream.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, u64, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     ringp, stagep = C.POINTER(RolloutRing), C.POINTER(RolloutStage)
-    lib.rollout_stream_post.argtypes = [i32, i32, ringp, vp, vp, vp, i32, vp, stagep, vp, f32, f32, vp, vp]
-    lib.rollout_stream_close.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, stagep, ringp, vp, vp, vp]
+    lib.rollout_stream_step.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, stagep, ringp, i32, vp, vp, vp, f32, f32, vp, vp]
     lib.rollout_last_hip_error.argtypes = []
     lib._typed = True
     return lib
@@ -214,6 +213,7 @@ def vdn_ops():
     lib.vdn_td_backward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.vdn_td_forward_packed.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
     lib.vdn_td_backward_packed.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp]
+    lib.vdn_gather_units.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp]
     pp, pl = C.POINTER(C.c_void_p), C.POINTER(C.c_int64)
     f64 = C.c_double
     lib.vdn_clip_adam_step.argtypes = [i32, pp, pp, pp, pp, pl, f32, f64, f64, f64, f64, f64, f64, vp, vp, vp]

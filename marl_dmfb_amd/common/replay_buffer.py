@@ -6,7 +6,7 @@ and uniform sampling WITH replacement follow the reference; sampling indices are
 device so `sample` never synchronises the host.
 
 The continuous rollout (common/rollout.py: generate_steps) writes finished episodes into the ring ON THE DEVICE
-(include/rollout_ops.h: rollout_stream_post / rollout_stream_close); cursor, fill level and every slot's episode length then
+(include/rollout_ops.h: rollout_stream_step); cursor, fill level and every slot's episode length then
 live in device tensors (`ring_state`, `ring_len`, `ring_stats`).  `sync_host` brings them to the host in one transfer per round;
 `draw` then picks the episodes of a learn on the HOST (uniform with replacement over the filled slots, as
 common/replay_buffer.py:53) and knows their lengths, so the learn is sized exactly (agent/agent.py:51-61) without a read-back."""

@@ -313,8 +313,10 @@ class RolloutWorker(Evaluator):
         st.ep_acc, st.chip_acc = z((E, 3), torch.float64), z((E, 4), torch.int64)
         st.close_slot = torch.full((E,), -1, dtype=torch.int32, device=dev)
         st.eps = z((1,), torch.float32)
+        st.state_alt = z((4,), torch.int64)
         st.stage = _lib.RolloutStage(st.t_ep.data_ptr(), st.o0.data_ptr(), st.o_next.data_ptr(), st.u.data_ptr(), st.onehot.data_ptr(),
-                                     st.r.data_ptr(), st.ep_acc.data_ptr(), st.chip_acc.data_ptr(), st.close_slot.data_ptr())
+                                     st.r.data_ptr(), st.ep_acc.data_ptr(), st.chip_acc.data_ptr(), st.close_slot.data_ptr(),
+                                     st.state_alt.data_ptr())
         st.ring = buffer.ring_struct()
         self._stream = st
         return st
@@ -329,7 +331,7 @@ class RolloutWorker(Evaluator):
     @torch.no_grad()
     def _play_stream(self, st, K):
         """K lock-steps of every chip: Q-network (front end, the two GRU GEMMs, gate math + fc1 + epsilon-greedy), the env
-        transition, rollout_stream_post / rollout_stream_close, reset of the chips whose episode ended."""
+        transition, rollout_stream_step (staging + episode close), reset of the chips whose episode ended."""
         import ctypes as C
         E, n, A, T = self.n_envs, self.n_agents, self.n_actions, self.episode_limit
         lib = self._ops()
@@ -364,20 +366,19 @@ class RolloutWorker(Evaluator):
             _, _, _, info = env.step(st.actions, uniforms=u, record=True, out=st.out[(s + 1) & 1])
             cons = info['constraints']
             cons_f64 = int(cons.dtype == torch.float64)
-            rc = lib.rollout_stream_post(E, T, C.byref(st.ring), vp(info['terminated'].data_ptr()), vp(info['team_reward'].data_ptr()),
-                                         vp(cons.data_ptr()), cons_f64, vp(info['success'].data_ptr()), C.byref(st.stage),
-                                         vp(st.eps.data_ptr()), anneal, float(self.min_epsilon), vp(self._draw.data_ptr()), stream)
-            if rc == 0:
-                rc = lib.rollout_stream_close(E, n, A, T, n * env.obs_len, st.hidden.shape[1], vp(cur.data_ptr()), vp(nxt.data_ptr()),
-                                              C.byref(st.stage), C.byref(st.ring), vp(st.hidden.data_ptr()),
-                                              vp(st.last_action.data_ptr()), stream)
+            rc = lib.rollout_stream_step(E, n, A, T, n * env.obs_len, st.hidden.shape[1], vp(cur.data_ptr()), vp(nxt.data_ptr()),
+                                         vp(info['terminated'].data_ptr()), vp(info['team_reward'].data_ptr()), vp(cons.data_ptr()),
+                                         cons_f64, vp(info['success'].data_ptr()), C.byref(st.stage), C.byref(st.ring), s & 1,
+                                         vp(st.hidden.data_ptr()), vp(st.last_action.data_ptr()), vp(st.eps.data_ptr()), anneal,
+                                         float(self.min_epsilon), vp(self._draw.data_ptr()), stream)
             if rc != 0:
-                raise RuntimeError('rollout_stream_post/close failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
+                raise RuntimeError('rollout_stream_step failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
             if self.stream_step_hook is not None:   # tests: (lock-step, actions, terminated) before the chips are reset
                 self.stream_step_hook(s, st.actions, info['terminated'])
             env.reset(mask=info['terminated'], obs=nxt)   # reset(new=False) of the chips whose episode ended (rollout.py:103)
-        if K & 1:
+        if K & 1:   # the double-buffered observation and ring state end in their second buffers
             st.obs[0].copy_(st.obs[1])
+            st.buffer.ring_state.copy_(st.state_alt)
 
     stream_step_hook = None
 

@@ -232,112 +232,106 @@ __global__ __launch_bounds__(kPostBlock) void k_post(int E, int T, int t, uint8_
 }
 
 // ---- continuous rollout (include/rollout_ops.h, "stream" entry points) --------------------------------------------------------
-// k_stream_post: ONE workgroup walks the chips in chunks of its size (4096 chips = four chunks), so that the ring slots of the
-// episodes that end in this lock-step are handed out in chip order by a block-wide scan: the ring's content does not depend on
-// scheduling (graph replay == eager play, bit for bit).
-constexpr int kStreamBlock = 1024;
-__global__ __launch_bounds__(kStreamBlock) void k_stream_post(int E, int T, int S, const uint8_t *__restrict__ term, const double *__restrict__ team_reward,
-                                                             const void *__restrict__ constraints, int cons_f64, const uint8_t *__restrict__ success,
-                                                             const int32_t *__restrict__ t_ep, float *__restrict__ stage_r, double *__restrict__ ep_acc,
-                                                             int64_t *__restrict__ chip_acc, int64_t *__restrict__ ring_state,
-                                                             int32_t *__restrict__ close_slot, int32_t *__restrict__ ring_len,
-                                                             double *__restrict__ ring_stats, float *__restrict__ eps_p, float anneal, float min_eps,
-                                                             uint32_t *__restrict__ draw_p) {
-    __shared__ int s_wave[kStreamBlock / 64];
-    __shared__ long s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long cursor0 = ring_state[0];
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int e0 = 0; e0 < E; e0 += kStreamBlock) {
-        const int e = e0 + tid;
-        const bool in = e < E;
-        const bool tm = in && term[e] != 0;
-        double rew = 0.0, cons = 0.0, succ = 0.0;
-        int t = 0;
-        if (in) {
-            t = t_ep[e];
-            const double tr = team_reward[e];
-            stage_r[(size_t)e * T + t] = (float)tr;
-            rew = ep_acc[(size_t)e * 3] + tr;
-            cons = ep_acc[(size_t)e * 3 + 1] + (cons_f64 ? ((const double *)constraints)[e] : (double)((const int32_t *)constraints)[e]);
-            succ = ep_acc[(size_t)e * 3 + 2] + (double)success[e];
-            ep_acc[(size_t)e * 3] = tm ? 0.0 : rew;
-            ep_acc[(size_t)e * 3 + 1] = tm ? 0.0 : cons;
-            ep_acc[(size_t)e * 3 + 2] = tm ? 0.0 : succ;
-            chip_acc[(size_t)e * 4 + 3] += 1;   // env steps played
-        }
-        const unsigned long long m = __ballot(tm);
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wave[wave] = __popcll(m);
-        __syncthreads();
-        long off = s_base;
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
-        if (in) {
-            int slot = -1;
-            if (tm) {
-                slot = (int)((cursor0 + off + rank) % S);
-                const int len = t + 1;
-                const long infl = succ > 0.0 ? len : T;   // `steps` is forced to episode_limit when not successful (rollout.py:148-149)
-                ring_len[slot] = len;
-                ring_stats[(size_t)slot * 4] = rew;
-                ring_stats[(size_t)slot * 4 + 1] = (double)infl;
-                ring_stats[(size_t)slot * 4 + 2] = cons;
-                ring_stats[(size_t)slot * 4 + 3] = succ;
-                chip_acc[(size_t)e * 4] += 1;
-                chip_acc[(size_t)e * 4 + 1] += infl;
-                chip_acc[(size_t)e * 4 + 2] += succ > 0.0 ? 1 : 0;
-            }
-            close_slot[e] = slot;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int w = 0; w < kStreamBlock / 64; ++w) tot += s_wave[w];
-            s_base += tot;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const long closed = s_base;
-        ring_state[0] = (cursor0 + closed) % S;
-        ring_state[1] = min((long)S, ring_state[1] + closed);
-        ring_state[2] += closed;
-        if (anneal > 0.0f) *eps_p = fmaxf(*eps_p - anneal * (float)E, min_eps);   // every chip played a step (rollout.py:126-127)
-        if (draw_p) *draw_p += 1u;
-    }
-}
-
 struct RingPtrs {
     int8_t *o, *o_next, *u, *u_onehot, *avail_u, *avail_u_next;
     float *r;
     uint8_t *padded, *terminated;
+    int32_t *len;
+    double *stats;
 };
 
-// One workgroup per chip.  (1) the chip's row of this lock-step is appended to its staged episode; (2) if its episode ended, the
-// staged episode is written into its ring slot with the padding rules of rollout.py:131-141 (zeros, padded = terminated = 1,
-// avail 0 behind the end), and the chip's recurrent state is cleared for the next episode (policy.init_hidden, rollout.py:112).
+// bytes != 0 among the four of a word
+__device__ __forceinline__ int nz_bytes(uint32_t w) { return __popc((w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u); }
+
+// One workgroup per chip.  (1) the chip's row of this lock-step is appended to its staged episode and its running sums advance;
+// (2) if its episode ended, its ring slot is (cursor + number of LOWER-numbered chips that also ended in this lock-step) -- every
+// closing workgroup counts the flags below its own chip, so the slots are handed out in chip order whatever the scheduling (graph
+// replay == eager play, bit for bit) and no single workgroup walks all the chips; the staged episode is written into the slot
+// with the padding rules of rollout.py:131-141 (zeros, padded = terminated = 1, avail 0 behind the end), and the chip's recurrent
+// state is cleared for the next episode (policy.init_hidden, rollout.py:112).  The workgroup of the LAST chip counts all flags
+// and publishes the new cursor / fill level / episode count, epsilon and the draw counter; the ring state is double-buffered
+// (state_in is only read, state_out only written) because the other workgroups read the cursor while it does.
 template <typename V>
-__global__ __launch_bounds__(256) void k_stream_close(int E, int n, int A, int T, int row_v, int H, const V *__restrict__ obs_prev,
-                                                      const V *__restrict__ obs_new, const int32_t *__restrict__ close_slot,
-                                                      int32_t *__restrict__ t_ep, V *__restrict__ stage_o0, V *__restrict__ stage_o_next,
-                                                      const int8_t *__restrict__ stage_u, const int8_t *__restrict__ stage_onehot,
-                                                      const float *__restrict__ stage_r, RingPtrs ring, float *__restrict__ hidden,
-                                                      int8_t *__restrict__ last_onehot) {
+__global__ __launch_bounds__(256) void k_stream_step(int E, int n, int A, int T, int S, int row_v, int H, const V *__restrict__ obs_prev,
+                                                     const V *__restrict__ obs_new, const uint8_t *__restrict__ term,
+                                                     const double *__restrict__ team_reward, const void *__restrict__ constraints, int cons_f64,
+                                                     const uint8_t *__restrict__ success, int32_t *__restrict__ t_ep, V *__restrict__ stage_o0,
+                                                     V *__restrict__ stage_o_next, const int8_t *__restrict__ stage_u,
+                                                     const int8_t *__restrict__ stage_onehot, float *__restrict__ stage_r,
+                                                     double *__restrict__ ep_acc, int64_t *__restrict__ chip_acc, int32_t *__restrict__ close_slot,
+                                                     RingPtrs ring, const int64_t *__restrict__ state_in, int64_t *__restrict__ state_out,
+                                                     float *__restrict__ hidden, int8_t *__restrict__ last_onehot, float *__restrict__ eps_p,
+                                                     float anneal, float min_eps, uint32_t *__restrict__ draw_p) {
+    __shared__ int s_cnt[4];
     const int e = blockIdx.x, tid = threadIdx.x;
-    const int t = t_ep[e], slot = close_slot[e];
+    const int t = t_ep[e];
+    const bool tm = term[e] != 0;
     const V *on = obs_new + (size_t)e * row_v, *op = obs_prev + (size_t)e * row_v;
     V *so = stage_o_next + (size_t)e * T * row_v;
     for (int k = tid; k < row_v; k += 256) {
         so[(size_t)t * row_v + k] = on[k];
         if (t == 0) stage_o0[(size_t)e * row_v + k] = op[k];
     }
-    __syncthreads();  // t_ep[e] / close_slot[e] were read by every thread before thread 0 rewrites t_ep
-    if (slot < 0) {
-        if (tid == 0) t_ep[e] = t + 1;
+    double rew = 0.0, cons = 0.0, succ = 0.0;
+    if (tid == 0) {
+        const double tr = team_reward[e];
+        stage_r[(size_t)e * T + t] = (float)tr;
+        rew = ep_acc[(size_t)e * 3] + tr;
+        cons = ep_acc[(size_t)e * 3 + 1] + (cons_f64 ? ((const double *)constraints)[e] : (double)((const int32_t *)constraints)[e]);
+        succ = ep_acc[(size_t)e * 3 + 2] + (double)success[e];
+        ep_acc[(size_t)e * 3] = tm ? 0.0 : rew;
+        ep_acc[(size_t)e * 3 + 1] = tm ? 0.0 : cons;
+        ep_acc[(size_t)e * 3 + 2] = tm ? 0.0 : succ;
+        chip_acc[(size_t)e * 4 + 3] += 1;   // env steps played
+    }
+    const bool last = e == E - 1;
+    if (!tm && !last) {   // (uniform) the episode goes on
+        if (tid == 0) { t_ep[e] = t + 1; close_slot[e] = -1; }
         return;
     }
+    // rank = chips below e whose episode ended too (16 flag bytes per thread and pass)
+    int c = 0;
+    for (int i = tid * 16; i < e; i += 256 * 16) {
+        if (i + 16 <= e && ((size_t)(term + i) & 15) == 0) {
+            const uint4 w = *(const uint4 *)(term + i);
+            c += nz_bytes(w.x) + nz_bytes(w.y) + nz_bytes(w.z) + nz_bytes(w.w);
+        } else {
+            for (int k = i; k < min(i + 16, e); ++k) c += term[k] != 0;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = c;
+    __syncthreads();
+    const int rank = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    const long cursor0 = state_in[0];
+    if (last && tid == 0) {
+        const long closed = rank + (tm ? 1 : 0);
+        state_out[0] = (cursor0 + closed) % S;
+        state_out[1] = min((long)S, state_in[1] + closed);
+        state_out[2] = state_in[2] + closed;
+        state_out[3] = state_in[3];
+        if (anneal > 0.0f) *eps_p = fmaxf(*eps_p - anneal * (float)E, min_eps);   // every chip played a step (rollout.py:126-127)
+        if (draw_p) *draw_p += 1u;
+    }
+    if (!tm) {
+        if (tid == 0) { t_ep[e] = t + 1; close_slot[e] = -1; }
+        return;
+    }
+    const int slot = (int)((cursor0 + rank) % S);
     const int len = t + 1;
+    if (tid == 0) {
+        const long infl = succ > 0.0 ? len : T;   // `steps` is forced to episode_limit when not successful (rollout.py:148-149)
+        ring.len[slot] = len;
+        ring.stats[(size_t)slot * 4] = rew;
+        ring.stats[(size_t)slot * 4 + 1] = (double)infl;
+        ring.stats[(size_t)slot * 4 + 2] = cons;
+        ring.stats[(size_t)slot * 4 + 3] = succ;
+        chip_acc[(size_t)e * 4] += 1;
+        chip_acc[(size_t)e * 4 + 1] += infl;
+        chip_acc[(size_t)e * 4 + 2] += succ > 0.0 ? 1 : 0;
+        close_slot[e] = slot;
+        t_ep[e] = 0;
+    }
     // o[tt] = first observation (tt == 0) or o_next[tt - 1]; o_next[tt] as staged; this step's row comes from obs_new (the
     // staged copy above was written by other threads of this workgroup)
     V *ro = (V *)ring.o + (size_t)slot * T * row_v, *rn = (V *)ring.o_next + (size_t)slot * T * row_v;
@@ -361,13 +355,12 @@ __global__ __launch_bounds__(256) void k_stream_close(int E, int n, int A, int T
     }
     for (int i = tid; i < T * n; i += 256) ring.u[(size_t)slot * T * n + i] = i / n < len ? stage_u[(size_t)e * T * n + i] : (int8_t)0;
     for (int tt = tid; tt < T; tt += 256) {
-        ring.r[(size_t)slot * T + tt] = tt < len ? stage_r[(size_t)e * T + tt] : 0.0f;
+        ring.r[(size_t)slot * T + tt] = tt < len ? (tt == t ? (float)team_reward[e] : stage_r[(size_t)e * T + tt]) : 0.0f;
         ring.padded[(size_t)slot * T + tt] = (uint8_t)(tt >= len);
         ring.terminated[(size_t)slot * T + tt] = (uint8_t)(tt >= len - 1);
     }
     for (int i = tid; i < n * H; i += 256) hidden[(size_t)e * n * H + i] = 0.0f;
     for (int i = tid; i < n * A; i += 256) last_onehot[(size_t)e * n * A + i] = 0;
-    if (tid == 0) t_ep[e] = 0;
 }
 
 thread_local int g_last = 0;
@@ -492,45 +485,38 @@ int rollout_gru_head_select_stream(const float *d_igates, const float *d_hgates,
                                 nullptr, stream, d_t_ep);
 }
 
-int rollout_stream_post(int32_t n_envs, int32_t episode_limit, const rollout_ring *ring, const uint8_t *d_term,
+int rollout_stream_step(int32_t n_envs, int32_t n_agents, int32_t n_actions, int32_t episode_limit, int32_t obs_row_bytes,
+                        int32_t hidden, const int8_t *d_obs_prev, const int8_t *d_obs_new, const uint8_t *d_term,
                         const double *d_team_reward, const void *d_constraints, int32_t constraints_f64, const uint8_t *d_success,
-                        const rollout_stage *stage, float *d_epsilon, float anneal, float min_epsilon, uint32_t *d_draw, void *stream) {
-    if (!ring || !stage || !d_term || !d_team_reward || !d_constraints || !d_success || n_envs < 0 || episode_limit < 1 ||
-        ring->slots < 1 || !ring->d_len || !ring->d_stats || !ring->d_state || !stage->d_t_ep || !stage->d_r || !stage->d_ep_acc ||
-        !stage->d_chip_acc || !stage->d_close_slot || (anneal > 0.0f && !d_epsilon))
-        return ROLLOUT_ERR_BAD_ARG;
-    if (n_envs == 0) return ROLLOUT_OK;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(k_stream_post, dim3(1), dim3(kStreamBlock), 0, (hipStream_t)stream, n_envs, episode_limit, ring->slots, d_term,
-                       d_team_reward, d_constraints, constraints_f64, d_success, stage->d_t_ep, stage->d_r, stage->d_ep_acc,
-                       stage->d_chip_acc, ring->d_state, stage->d_close_slot, ring->d_len, ring->d_stats, d_epsilon, anneal, min_epsilon,
-                       d_draw);
-    return finish();
-}
-
-int rollout_stream_close(int32_t n_envs, int32_t n_agents, int32_t n_actions, int32_t episode_limit, int32_t obs_row_bytes,
-                         int32_t hidden, const int8_t *d_obs_prev, const int8_t *d_obs_new, const rollout_stage *stage,
-                         const rollout_ring *ring, float *d_hidden, int8_t *d_last_onehot, void *stream) {
-    if (!ring || !stage || !d_obs_prev || !d_obs_new || !d_hidden || !d_last_onehot || n_envs < 0 || n_agents < 1 || n_actions < 1 ||
-        episode_limit < 1 || obs_row_bytes < 1 || hidden < 1 || !stage->d_t_ep || !stage->d_close_slot || !stage->d_o0 ||
-        !stage->d_o_next || !stage->d_u || !stage->d_onehot || !stage->d_r || !ring->d_o || !ring->d_o_next || !ring->d_u ||
-        !ring->d_u_onehot || !ring->d_avail_u || !ring->d_avail_u_next || !ring->d_r || !ring->d_padded || !ring->d_terminated)
+                        const rollout_stage *stage, const rollout_ring *ring, int32_t parity, float *d_hidden, int8_t *d_last_onehot,
+                        float *d_epsilon, float anneal, float min_epsilon, uint32_t *d_draw, void *stream) {
+    if (!ring || !stage || !d_obs_prev || !d_obs_new || !d_term || !d_team_reward || !d_constraints || !d_success || !d_hidden ||
+        !d_last_onehot || n_envs < 0 || n_agents < 1 || n_actions < 1 || episode_limit < 1 || obs_row_bytes < 1 || hidden < 1 ||
+        ring->slots < 1 || !stage->d_t_ep || !stage->d_close_slot || !stage->d_o0 || !stage->d_o_next || !stage->d_u || !stage->d_onehot ||
+        !stage->d_r || !stage->d_ep_acc || !stage->d_chip_acc || !stage->d_state_alt || !ring->d_o || !ring->d_o_next || !ring->d_u ||
+        !ring->d_u_onehot || !ring->d_avail_u || !ring->d_avail_u_next || !ring->d_r || !ring->d_padded || !ring->d_terminated ||
+        !ring->d_len || !ring->d_stats || !ring->d_state || (anneal > 0.0f && !d_epsilon))
         return ROLLOUT_ERR_BAD_ARG;
     if (n_envs == 0) return ROLLOUT_OK;
     const RingPtrs rp{ring->d_o, ring->d_o_next, ring->d_u, ring->d_u_onehot, ring->d_avail_u, ring->d_avail_u_next, ring->d_r,
-                      ring->d_padded, ring->d_terminated};
+                      ring->d_padded, ring->d_terminated, ring->d_len, ring->d_stats};
+    const int64_t *st_in = parity ? stage->d_state_alt : ring->d_state;
+    int64_t *st_out = parity ? ring->d_state : stage->d_state_alt;
     const bool dw = obs_row_bytes % 4 == 0 &&
                     ((size_t)d_obs_prev | (size_t)d_obs_new | (size_t)stage->d_o0 | (size_t)stage->d_o_next | (size_t)ring->d_o | (size_t)ring->d_o_next) % 4 == 0;
     (void)hipGetLastError();
     if (dw)
-        hipLaunchKernelGGL((k_stream_close<uint32_t>), dim3((unsigned)n_envs), dim3(256), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
-                           episode_limit, obs_row_bytes / 4, hidden, (const uint32_t *)d_obs_prev, (const uint32_t *)d_obs_new,
-                           stage->d_close_slot, stage->d_t_ep, (uint32_t *)stage->d_o0, (uint32_t *)stage->d_o_next, stage->d_u,
-                           stage->d_onehot, stage->d_r, rp, d_hidden, d_last_onehot);
+        hipLaunchKernelGGL((k_stream_step<uint32_t>), dim3((unsigned)n_envs), dim3(256), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
+                           episode_limit, ring->slots, obs_row_bytes / 4, hidden, (const uint32_t *)d_obs_prev, (const uint32_t *)d_obs_new,
+                           d_term, d_team_reward, d_constraints, constraints_f64, d_success, stage->d_t_ep, (uint32_t *)stage->d_o0,
+                           (uint32_t *)stage->d_o_next, stage->d_u, stage->d_onehot, stage->d_r, stage->d_ep_acc, stage->d_chip_acc,
+                           stage->d_close_slot, rp, st_in, st_out, d_hidden, d_last_onehot, d_epsilon, anneal, min_epsilon, d_draw);
     else
-        hipLaunchKernelGGL((k_stream_close<int8_t>), dim3((unsigned)n_envs), dim3(256), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
-                           episode_limit, obs_row_bytes, hidden, d_obs_prev, d_obs_new, stage->d_close_slot, stage->d_t_ep, stage->d_o0,
-                           stage->d_o_next, stage->d_u, stage->d_onehot, stage->d_r, rp, d_hidden, d_last_onehot);
+        hipLaunchKernelGGL((k_stream_step<int8_t>), dim3((unsigned)n_envs), dim3(256), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
+                           episode_limit, ring->slots, obs_row_bytes, hidden, d_obs_prev, d_obs_new, d_term, d_team_reward, d_constraints,
+                           constraints_f64, d_success, stage->d_t_ep, stage->d_o0, stage->d_o_next, stage->d_u, stage->d_onehot, stage->d_r,
+                           stage->d_ep_acc, stage->d_chip_acc, stage->d_close_slot, rp, st_in, st_out, d_hidden, d_last_onehot, d_epsilon,
+                           anneal, min_epsilon, d_draw);
     return finish();
 }
 

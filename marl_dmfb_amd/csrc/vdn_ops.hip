@@ -102,6 +102,16 @@ __global__ __launch_bounds__(256) void k_td_backward_packed(const float *__restr
     for (int a = 0; a < A; ++a) gq[row * A + a] = (bad_a || a == a_taken) ? d : 0.0f;
 }
 
+// dst unit j = src unit units[j] + shift (zeros for j < zero_below): coalesced copies of whole units (n rows of the replay tensors)
+template <typename V>
+__global__ __launch_bounds__(256) void k_gather_units(const V *__restrict__ src, int unit_v, const int32_t *__restrict__ units, int U, int shift,
+                                                      int zero_below, V *__restrict__ dst) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)U * unit_v) return;
+    const int j = (int)(idx / unit_v), k = (int)(idx - (long)j * unit_v);
+    dst[idx] = j < zero_below ? (V)0 : src[((size_t)units[j] + shift) * unit_v + k];
+}
+
 }  // namespace
 
 namespace {
@@ -268,6 +278,25 @@ int vdn_td_backward_packed(const float *d_mtd, const float *d_mask, const int32_
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_td_backward_packed, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_mtd, d_mask, d_units,
                        d_u, d_grad_num, rows, n_agents, n_actions, d_grad_q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last = (int)e; return VDN_ERR_HIP; }
+    return VDN_OK;
+}
+
+int vdn_gather_units(const void *d_src, int32_t unit_bytes, const int32_t *d_units, int32_t n_units, int32_t unit_shift,
+                     int32_t zero_below, void *d_dst, void *stream) {
+    if (!d_src || !d_units || !d_dst || unit_bytes < 1 || n_units < 0 || zero_below < 0) return VDN_ERR_BAD_ARG;
+    if (n_units == 0) return VDN_OK;
+    (void)hipGetLastError();
+    const bool dw = unit_bytes % 4 == 0 && ((size_t)d_src | (size_t)d_dst) % 4 == 0;
+    const int uv = dw ? unit_bytes / 4 : unit_bytes;
+    const long total = (long)n_units * uv;
+    if (dw)
+        hipLaunchKernelGGL((k_gather_units<uint32_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint32_t *)d_src, uv, d_units, n_units, unit_shift, zero_below, (uint32_t *)d_dst);
+    else
+        hipLaunchKernelGGL((k_gather_units<uint8_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint8_t *)d_src, uv, d_units, n_units, unit_shift, zero_below, (uint8_t *)d_dst);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last = (int)e; return VDN_ERR_HIP; }
     return VDN_OK;

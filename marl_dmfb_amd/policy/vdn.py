@@ -353,7 +353,17 @@ class VDN:
         with torch.no_grad():
             return bool(hasattr(net, '_hip_conv_ok') and net._hip_conv_ok(probe) and net._hip_geometry() == 9)
 
-    def learn_packed(self, buffers, idx, lens, train_step):
+    @staticmethod
+    def pack_units(idx, lens, t_ring):
+        """Host side of learn_packed: (counts per step, unit list) of a length-sorted draw.  counts[t] = episodes longer than t;
+        units = for t = 0, 1, ...: slot * t_ring + t of those episodes (int32)."""
+        import numpy as np
+        idx, lens = np.asarray(idx, np.int64), np.asarray(lens, np.int64)
+        counts = (lens[None, :] > np.arange(int(lens[0]))[:, None]).sum(1)
+        units = np.concatenate([idx[:c] * t_ring + t for t, c in enumerate(counts)]).astype(np.int32)
+        return counts, units
+
+    def learn_packed(self, buffers, idx, lens, train_step, plan=None):
         """VDN.learn (policy/vdn.py:79-132) on the episodes in slots `idx` of the replay tensors `buffers`, WITHOUT their padded
         steps.  idx / lens: host integer arrays sorted by episode length, longest first (ReplayBuffer.draw).  The reference trims
         the batch to its longest episode (agent/agent.py:51-70) and multiplies the TD error of a padded step by 0
@@ -362,28 +372,31 @@ class VDN:
         the GRU sequence kernels stop every row at its own length, and the TD block indexes the replay tensors in place."""
         import numpy as np
         dev, n, A = self.device, self.n_agents, self.n_actions
-        idx, lens = np.asarray(idx, np.int64), np.asarray(lens, np.int64)
         B, T_ring, O = len(idx), buffers['o'].shape[1], buffers['o'].shape[-1]
-        Tm = int(lens[0])
-        counts = (lens[None, :] > np.arange(Tm)[:, None]).sum(1)            # episodes still running at step t (non-increasing)
-        units_np = np.concatenate([idx[:c] * T_ring + t for t, c in enumerate(counts)]).astype(np.int32)
-        U = int(units_np.shape[0])
+        if plan is None:   # (counts, device unit list) may come from the caller, who uploads the lists of a round's learns in one go
+            counts, units_np = self.pack_units(idx, lens, T_ring)
+            units = torch.from_numpy(units_np).to(dev, non_blocking=True)
+        else:
+            counts, units = plan
+        U = int(units.shape[0])
         V = U * n
         Vp = -(-V // PACK_ROWS) * PACK_ROWS
-        units = torch.from_numpy(units_np).to(dev, non_blocking=True)
-        rows = (units.to(torch.int64)[:, None] * n + torch.arange(n, device=dev)[None]).reshape(-1)   # rows of the (slot, t, agent) tensors
-        o_rows, on_rows = buffers['o'].view(-1, O), buffers['o_next'].view(-1, O)
-        oh_rows = buffers['u_onehot'].view(-1, A)
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.vdn_ops()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
-        def packed(src, sel, lo=0):
-            out = torch.empty((Vp, src.shape[1]), dtype=src.dtype, device=dev)
-            if lo:
-                out[:lo].zero_()
-            torch.index_select(src, 0, sel, out=out[lo:lo + sel.shape[0]])
-            out[lo + sel.shape[0]:].zero_()
+        def packed(src, shift=0, zero_below=0):   # (Vp, row) copy of the units' rows; rows V .. Vp-1 are zeros
+            row = src.shape[-1]
+            out = torch.empty((Vp, row), dtype=src.dtype, device=dev)
+            out[V:].zero_()
+            rc = lib.vdn_gather_units(C.c_void_p(src.data_ptr()), n * row * src.element_size(), C.c_void_p(units.data_ptr()), U, shift,
+                                      zero_below, C.c_void_p(out.data_ptr()), stream)
+            if rc != 0:
+                raise RuntimeError('vdn_gather_units failed: %d (hip %d)' % (rc, lib.vdn_last_hip_error()))
             return out
-        obs_e, obs_t, oh_t = packed(o_rows, rows), packed(on_rows, rows), packed(oh_rows, rows)
-        oh_e = packed(oh_rows, rows[B * n:] - n, lo=B * n)   # last action of step t = u_onehot[t - 1]; zeros at t == 0 (vdn.py:150-160)
+        obs_e, obs_t, oh_t = packed(buffers['o']), packed(buffers['o_next']), packed(buffers['u_onehot'])
+        oh_e = packed(buffers['u_onehot'], shift=-1, zero_below=B)   # last action of step t = u_onehot[t - 1]; zeros at t == 0 (vdn.py:150-160)
         x_e = self._features(self.eval_rnn, obs_e, oh_e)
         with torch.no_grad():
             x_t = self._features(self.target_rnn, obs_t, oh_t)

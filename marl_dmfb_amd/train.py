@@ -75,10 +75,11 @@ class Trainer:
         prefetched = []
         if self._packed is None:
             self._packed = bool(getattr(self.args, 'packed_learn', True) and hasattr(pol, 'packed_ok') and pol.packed_ok(self.buffer.buffers))
+        plans = self._upload_plans(draws) if (self._packed and learns) else None
         for k in range(learns):
             idx, lens = draws[k]
             if self._packed:   # the padded steps of the drawn episodes are never computed; the ring is read in place
-                pol.learn_packed(self.buffer.buffers, idx, lens, self.trained_times)
+                pol.learn_packed(self.buffer.buffers, idx, lens, self.trained_times, plan=plans[k])
                 self.trained_times += 1
                 continue
             mini_batch = prefetched.pop() if prefetched else self.buffer.gather(idx)
@@ -93,6 +94,27 @@ class Trainer:
         else:
             self._time_steps += inflated
         return played
+
+    def _upload_plans(self, draws):
+        """The (episode, step) unit lists of all the round's learns in ONE host -> device copy from pinned memory, queued while the
+        GPU is idle anyway (right behind the round's read): a pageable copy inside each learn would make the host wait for the
+        previous learn."""
+        import numpy as np
+        pol = self.agents.policy
+        T_ring = self.buffer.episode_limit
+        packs = [pol.pack_units(idx, lens, T_ring) for idx, lens in draws]
+        total = sum(int(u.shape[0]) for _, u in packs)
+        pin = getattr(self, '_pin_units', None)
+        if pin is None or pin.numel() < total:
+            pin = self._pin_units = torch.empty(max(total, len(draws) * self.args.batch_size * T_ring), dtype=torch.int32).pin_memory()
+        host = pin[:total]
+        host.copy_(torch.from_numpy(np.concatenate([u for _, u in packs])))
+        dev = host.to(self.rolloutWorker.device, non_blocking=True)
+        plans, off = [], 0
+        for counts, u in packs:
+            plans.append((counts, dev[off:off + u.shape[0]]))
+            off += u.shape[0]
+        return plans
 
     def _finish_dist_round(self, pol):
         if pol.ride_along_sum is None:  # no learn ran this round (train_time == 0): reduce the count by itself

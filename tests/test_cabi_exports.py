@@ -88,7 +88,9 @@ def test_crnn_ops_library_exports():
                      'crnn_front9_forward', 'crnn_front9_forward_live',
                      'crnn_front_padded_cols', 'crnn_last_hip_error']
     gru = sorted(set(re.findall(r'\b(gru_[a-z_0-9]+)\s*\(', txt)))
-    assert gru == ['gru_last_hip_error', 'gru_seq_backward', 'gru_seq_forward', 'gru_seq_row_blocks']
+    assert gru == ['gru_last_hip_error', 'gru_seq_backward', 'gru_seq_backward_packed', 'gru_seq_forward', 'gru_seq_forward_packed',
+                   'gru_seq_row_blocks']
+    assert lib.gru_seq_forward_packed(None, None, None, None, None, 4, 8, 128, None, None, None, None) == -1
     for n in names + gru:
         assert hasattr(lib, n)
     # argument guards run on the host before anything touches the GPU
@@ -104,9 +106,8 @@ def test_rollout_ops_library_exports():
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     names = sorted(set(re.findall(r'\b(rollout_[a-z_0-9]+)\s*\(', txt)))
     assert names == ['rollout_compact_alive', 'rollout_gru_head_select', 'rollout_gru_head_select_live', 'rollout_gru_head_select_stream',
-                     'rollout_last_hip_error', 'rollout_post_step', 'rollout_select_actions', 'rollout_stream_close', 'rollout_stream_post']
-    assert lib.rollout_stream_post(4, 10, None, None, None, None, 0, None, None, None, 0.0, 0.0, None, None) == -1
-    assert lib.rollout_stream_close(4, 2, 5, 10, 490, 128, None, None, None, None, None, None, None) == -1
+                     'rollout_last_hip_error', 'rollout_post_step', 'rollout_select_actions', 'rollout_stream_step']
+    assert lib.rollout_stream_step(4, 2, 5, 10, 490, 128, None, None, None, None, None, 0, None, None, None, 0, None, None, None, 0.0, 0.0, None, None) == -1
     assert lib.rollout_compact_alive(4, None, None, None, None) == -1
     for n in names:
         assert hasattr(lib, n)
@@ -118,7 +119,10 @@ def test_vdn_ops_library_exports():
     txt = open(os.path.join(ROOT, 'include', 'vdn_ops.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     names = sorted(set(re.findall(r'\b(vdn_[a-z_0-9]+)\s*\(', txt)))
-    assert names == ['vdn_clip_adam_step', 'vdn_last_hip_error', 'vdn_td_backward', 'vdn_td_forward']
+    assert names == ['vdn_clip_adam_step', 'vdn_gather_units', 'vdn_last_hip_error', 'vdn_td_backward', 'vdn_td_backward_packed', 'vdn_td_forward',
+                     'vdn_td_forward_packed']
+    assert lib.vdn_gather_units(None, 980, None, 4, 0, 0, None, None) == -1
+    assert lib.vdn_td_forward_packed(None, None, None, 4, None, None, None, None, None, 4, 5, 0.99, None, None, None, None) == -1
     for n in names:
         assert hasattr(lib, n)
     # argument guards run on the host before anything touches the GPU
