@@ -96,20 +96,13 @@ class Trainer:
         return played
 
     def _upload_plans(self, draws):
-        """The (episode, step) unit lists of all the round's learns in ONE host -> device copy from pinned memory, queued while the
-        GPU is idle anyway (right behind the round's read): a pageable copy inside each learn would make the host wait for the
-        previous learn."""
+        """The (episode, step) unit lists of all the round's learns in ONE host -> device copy, made while the GPU is idle anyway
+        (right behind the round's read).  A plain pageable copy: uploads from a persistent PINNED buffer with non_blocking=True made
+        later HIP calls of the round block for tens of milliseconds on MI355X / ROCm 7 (tools/dbg_round.py: 22.8 -> 33 ms per round)."""
         import numpy as np
         pol = self.agents.policy
-        T_ring = self.buffer.episode_limit
-        packs = [pol.pack_units(idx, lens, T_ring) for idx, lens in draws]
-        total = sum(int(u.shape[0]) for _, u in packs)
-        pin = getattr(self, '_pin_units', None)
-        if pin is None or pin.numel() < total:
-            pin = self._pin_units = torch.empty(max(total, len(draws) * self.args.batch_size * T_ring), dtype=torch.int32).pin_memory()
-        host = pin[:total]
-        host.copy_(torch.from_numpy(np.concatenate([u for _, u in packs])))
-        dev = host.to(self.rolloutWorker.device, non_blocking=True)
+        packs = [pol.pack_units(idx, lens, self.buffer.episode_limit) for idx, lens in draws]
+        dev = torch.from_numpy(np.concatenate([u for _, u in packs])).to(self.rolloutWorker.device)
         plans, off = [], 0
         for counts, u in packs:
             plans.append((counts, dev[off:off + u.shape[0]]))
