@@ -72,6 +72,7 @@ def parse(argv=None):
     ap.add_argument('--no_graph', dest='graph', action='store_false',
                     help='play the rollout eagerly instead of replaying it as a captured HIP graph (the default)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--dump_weights', default='', help='rank 0 saves the eval network\'s state_dict here after the timed rounds (tests)')
     ap.add_argument('--no_tiers', action='store_true')
     ap.add_argument('--cpu_seconds', type=float, default=24.0, help='CPU seconds per process of the cpu_baseline sample (three phases)')
     ap.add_argument('--roofline_envs', type=int, default=655360,
@@ -693,6 +694,8 @@ def main(argv=None):
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
 
+    if a.dump_weights and rank == 0:
+        torch.save({k: v.detach().cpu() for k, v in pol.eval_rnn.state_dict().items()}, a.dump_weights)
     tot = torch.tensor([float(played), dt], device=device, dtype=torch.float64)
     if dist:
         p = tot[0:1].clone() if backend == 'nccl' else tot[0:1].cpu()

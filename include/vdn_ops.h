@@ -70,8 +70,12 @@ int vdn_gather_units(const void *d_src, int32_t unit_bytes, const int32_t *d_uni
  *   total = sqrt(sum over all tensors of sum(g^2));  c = min(1, max_norm / (total + 1e-6));  g' = g * c
  *   m = m + (1 - beta1) * (g' - m);  v = beta2 * v + (1 - beta2) * g' * g';
  *   p -= (lr / bias_correction1) * m / (sqrt(v) / sqrt(bias_correction2) + eps)
- * (torch's formulas; bias_correction = 1 - beta^step is computed by the caller; the scalars are doubles and enter the float
- * element arithmetic where torch's do: 1 - beta and lr / bias_correction1 rounded to float once, the denominator formed in double).  The gradients are rescaled in memory as well
+ * (torch's formulas and element arithmetic: bias_correction = 1 - beta^step is computed by the caller in double; 1 - beta,
+ * lr / bias_correction1, sqrt(bias_correction2) and eps are rounded to float once and every element operation is a float operation
+ * in torch's order: m.lerp, v = beta2 v + ((1 - beta2) g) g, p += -step (m / denom)).  A NaN norm makes every gradient NaN, as
+ * clip_grad_norm_ does.  d_grad_div (device float, may be NULL): every gradient is first divided by *d_grad_div -- VDN.learn
+ * differentiates the UN-normalised loss sum((mask td)^2) and divides by the mask count here (policy/vdn.py:122), the same
+ * arithmetic with and without data parallelism (there the count is the all-reduced one).  The gradients are rescaled in memory as well
  * (clip_grad_norm_ leaves g' in p.grad).  d_partials: VDN_NORM_BLOCKS floats of scratch;
  * *d_total_norm receives `total` (the value clip_grad_norm_ returns).  The pointer arrays are HOST arrays of DEVICE pointers. */
 #define VDN_MAX_TENSORS 32
@@ -79,7 +83,7 @@ int vdn_gather_units(const void *d_src, int32_t unit_bytes, const int32_t *d_uni
 int vdn_clip_adam_step(int32_t n_tensors, float *const *params, float *const *grads, float *const *exp_avg,
                        float *const *exp_avg_sq, const int64_t *numel, float max_norm, double lr, double beta1, double beta2,
                        double eps, double bias_correction1, double bias_correction2, float *d_partials, float *d_total_norm,
-                       void *stream);
+                       const float *d_grad_div, void *stream);
 
 int vdn_last_hip_error(void);
 

@@ -216,7 +216,7 @@ def vdn_ops():
     lib.vdn_gather_units.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp]
     pp, pl = C.POINTER(C.c_void_p), C.POINTER(C.c_int64)
     f64 = C.c_double
-    lib.vdn_clip_adam_step.argtypes = [i32, pp, pp, pp, pp, pl, f32, f64, f64, f64, f64, f64, f64, vp, vp, vp]
+    lib.vdn_clip_adam_step.argtypes = [i32, pp, pp, pp, pp, pl, f32, f64, f64, f64, f64, f64, f64, vp, vp, vp, vp]
     lib.vdn_last_hip_error.argtypes = []
     lib._typed = True
     return lib

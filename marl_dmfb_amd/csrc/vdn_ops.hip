@@ -131,7 +131,7 @@ __device__ __forceinline__ void locate(const TensorList &tl, long i, int &k) {
     while (i >= tl.off[k + 1]) ++k;
 }
 
-__global__ __launch_bounds__(256) void k_sqnorm_partials(TensorList tl, float *__restrict__ partials) {
+__global__ __launch_bounds__(256) void k_sqnorm_partials(TensorList tl, float *__restrict__ partials, const float *__restrict__ grad_div) {
     __shared__ float s_w[4];
     const long total = tl.off[tl.n];
     const long per = (total + gridDim.x - 1) / gridDim.x;
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void k_sqnorm_partials(TensorList tl, float *_
     int k = 0;
     for (long i = lo + threadIdx.x; i < hi; i += 256) {
         locate(tl, i, k);
-        const float g = tl.g[k][i - tl.off[k]];
+        float g = tl.g[k][i - tl.off[k]];
+        if (grad_div) g = g / grad_div[0];
         acc = fmaf(g, g, acc);
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(256) void k_sqnorm_partials(TensorList tl, float *_
 }
 
 __global__ __launch_bounds__(256) void k_clip_adam(TensorList tl, const float *__restrict__ partials, int n_partials, float max_norm,
-                                                   float step_size, float omb1, float beta2, float omb2, double eps, double bc2_sqrt,
-                                                   float *__restrict__ total_norm) {
+                                                   float step_size, float omb1, float beta2, float omb2, float eps, float bc2_sqrt,
+                                                   float *__restrict__ total_norm, const float *__restrict__ grad_div) {
     __shared__ float s_coef;
     if (threadIdx.x < 64) {  // every workgroup adds the partial sums in the same fixed order
         float t = 0.0f;
@@ -159,7 +160,8 @@ __global__ __launch_bounds__(256) void k_clip_adam(TensorList tl, const float *_
         for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
         if (threadIdx.x == 0) {
             const float norm = sqrtf(t);
-            s_coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
+            // clamp(max_norm / (norm + 1e-6), max = 1) of clip_grad_norm_; a NaN norm stays NaN in every gradient, as in torch
+            s_coef = norm != norm ? norm : fminf(max_norm / (norm + 1e-6f), 1.0f);
             if (blockIdx.x == 0) total_norm[0] = norm;
         }
     }
@@ -172,15 +174,19 @@ __global__ __launch_bounds__(256) void k_clip_adam(TensorList tl, const float *_
     for (long i = lo + threadIdx.x; i < hi; i += 256) {
         locate(tl, i, k);
         const long j = i - tl.off[k];
-        const float g = tl.g[k][j] * coef;
-        if (coef != 1.0f) tl.g[k][j] = g;  // clip_grad_norm_ leaves the rescaled gradient in p.grad
+        float g = tl.g[k][j];
+        if (grad_div) g = g / grad_div[0];  // the gradient of the un-normalised loss / the (global) mask count
+        g = g * coef;
+        if (grad_div || coef != 1.0f) tl.g[k][j] = g;  // clip_grad_norm_ leaves the rescaled gradient in p.grad
         float m = tl.m[k][j], v = tl.v[k][j];
         m = m + omb1 * (g - m);
         v = beta2 * v + omb2 * g * g;
         tl.m[k][j] = m;
         tl.v[k][j] = v;
-        const float denom = (float)((double)sqrtf(v) / bc2_sqrt + eps);  // torch forms the denominator with double scalars
-        tl.p[k][j] -= step_size * m / denom;
+        // torch's element arithmetic (foreach and fused Adam alike): float operations, the Python-double scalars rounded to float
+        // where they enter: denom = sqrt(v) / sqrt(bias_correction2) + eps;  p += -step_size * (m / denom)   (addcdiv)
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        tl.p[k][j] -= step_size * (m / denom);
     }
 }
 
@@ -191,7 +197,7 @@ extern "C" {
 int vdn_clip_adam_step(int32_t n_tensors, float *const *params, float *const *grads, float *const *exp_avg,
                        float *const *exp_avg_sq, const int64_t *numel, float max_norm, double lr, double beta1, double beta2,
                        double eps, double bias_correction1, double bias_correction2, float *d_partials, float *d_total_norm,
-                       void *stream) {
+                       const float *d_grad_div, void *stream) {
     if (n_tensors < 1 || n_tensors > VDN_MAX_TENSORS || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !d_partials ||
         !d_total_norm || !(bias_correction1 > 0.0) || !(bias_correction2 > 0.0))
         return VDN_ERR_BAD_ARG;
@@ -208,12 +214,12 @@ int vdn_clip_adam_step(int32_t n_tensors, float *const *params, float *const *gr
         tl.off[k + 1] = tl.off[k] + (on ? (long)numel[k] : 0);
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_sqnorm_partials, dim3(VDN_NORM_BLOCKS), dim3(256), 0, (hipStream_t)stream, tl, d_partials);
+    hipLaunchKernelGGL(k_sqnorm_partials, dim3(VDN_NORM_BLOCKS), dim3(256), 0, (hipStream_t)stream, tl, d_partials, d_grad_div);
     const long total = tl.off[n_tensors];
     const int blocks = (int)((total + 1023) / 1024 < 1024 ? (total + 1023) / 1024 : 1024);
     hipLaunchKernelGGL(k_clip_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tl, d_partials, VDN_NORM_BLOCKS, max_norm,
-                       (float)((double)lr / bias_correction1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (double)eps,
-                       sqrt(bias_correction2), d_total_norm);
+                       (float)((double)lr / bias_correction1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)sqrt(bias_correction2), d_total_norm, d_grad_div);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last = (int)e; return VDN_ERR_HIP; }
     return VDN_OK;

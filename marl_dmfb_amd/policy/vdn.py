@@ -252,8 +252,9 @@ class VDN:
         return flat
 
     def _allreduce_grads(self, mask_sum):
-        """ONE collective per learn step: [all gradients of the un-normalised loss, mask count, ride-along scalars].
-        Flatten = one concatenation, un-flatten = one scale + one multi-tensor copy, so a rank adds ~4 launches to the
+        """ONE collective per learn step: [all gradients of the un-normalised loss, mask count, ride-along scalars].  Leaves the
+        SUMMED gradients in p.grad and returns the summed mask count (device scalar).
+        Flatten = one concatenation, un-flatten = one multi-tensor copy, so a rank adds ~3 launches to the
         all-reduce.  `overlap_hook` (set by the Trainer: the NEXT learn's replay sample, which does not depend on this learn)
         is queued while the collective is in flight; with `allreduce_events` set to a list every collective is bracketed by a
         HIP event pair on the compute stream (bench.py: allreduce_ms_per_learn)."""
@@ -276,8 +277,7 @@ class VDN:
         if extra is not None:
             self.ride_along_sum = flat[n + 1:].clone()
             self.ride_along = None
-        total = flat[n].clone()
-        flat[:n].div_(total)
+        total = flat[n].clone()   # the global mask count: the caller divides by it (in the clip + Adam kernel: _fused_step)
         views, off = [], 0
         for p in params:
             views.append(flat[off:off + p.numel()].view_as(p))
@@ -297,15 +297,7 @@ class VDN:
                 self._td_bad = torch.zeros(1, dtype=torch.int32, device=dev)
             num, mask_sum = _TDLoss.apply(q_e, q_t, batch['u'], batch['r'], batch['avail_u_next'], batch['terminated'],
                                           batch['padded'], T, self.args.gamma, self._td_bad)
-            self.optimizer.zero_grad()
-            if self.dist:
-                num.backward()
-                total = self._allreduce_grads(mask_sum)
-                loss = num.detach() / total
-            else:
-                loss = num / mask_sum
-                loss.backward()
-            return self._step_and_sync(loss, train_step)
+            return self._backward_and_step(num, mask_sum, train_step)
         u = _t(batch['u'], dev, torch.long)[:, :T]
         r = _t(batch['r'], dev, torch.float32)[:, :T]
         avail_u_next = _t(batch['avail_u_next'], dev, torch.float32)[:, :T]
@@ -329,11 +321,20 @@ class VDN:
             num = (masked_td_error ** 2).sum()
             num.backward()
             total = self._allreduce_grads(mask.sum())
-            loss = num.detach() / total
-        else:
-            loss = (masked_td_error ** 2).sum() / mask.sum()
-            loss.backward()
+            return self._step_and_sync(num.detach() / total, train_step, grad_div=total)
+        loss = (masked_td_error ** 2).sum() / mask.sum()
+        loss.backward()
         return self._step_and_sync(loss, train_step)
+
+    def _backward_and_step(self, num, mask_sum, train_step):
+        """loss = num / mask_sum (policy/vdn.py:122), backward, clip, step.  The un-normalised num is differentiated and the
+        division by the mask count happens inside the clip + Adam kernel (include/vdn_ops.h: d_grad_div), so that one rank and
+        many ranks (where the count is the all-reduced one) run the same arithmetic: a one-rank data-parallel run reproduces the
+        plain run bit for bit (tests/test_gpu_dist_learn.py)."""
+        self.optimizer.zero_grad()
+        num.backward()
+        total = self._allreduce_grads(mask_sum) if self.dist else mask_sum
+        return self._step_and_sync(num.detach() / total, train_step, grad_div=total)
 
     def packed_ok(self, buffers):
         """learn_packed applies to the replay ring on the GPU (int8 / float32 / bool episode tensors), the fov-9 CRNN with the HIP
@@ -408,15 +409,7 @@ class VDN:
             self._td_bad = torch.zeros(1, dtype=torch.int32, device=dev)
         num, mask_sum = _TDLossPacked.apply(q_e, q_t, units, U, buffers['u'], buffers['r'], buffers['avail_u_next'],
                                             buffers['terminated'], buffers['padded'], n, A, self.args.gamma, self._td_bad)
-        self.optimizer.zero_grad()
-        if self.dist:
-            num.backward()
-            total = self._allreduce_grads(mask_sum)
-            loss = num.detach() / total
-        else:
-            loss = num / mask_sum
-            loss.backward()
-        return self._step_and_sync(loss, train_step)
+        return self._backward_and_step(num, mask_sum, train_step)
 
     def check_td_inputs(self):
         """Raises if any learn since the last call met an action outside [0, n_actions) -- the input torch.gather raises on in
@@ -428,20 +421,25 @@ class VDN:
                 self._td_bad.zero_()
                 raise RuntimeError('VDN.learn: %d (episode, step) slots with an action outside [0, %d)' % (bad, self.n_actions))
 
-    def _fused_step(self):
+    def _fused_step(self, grad_div=None):
         """clip_grad_norm_ + Adam.step as two launches (include/vdn_ops.h: vdn_clip_adam_step) instead of torch's ~11 small
         ones; same formulas.  Returns False (torch path) when it does not apply: not the GPU Adam of policy/vdn.py:67-68, a
         non-float32 / non-contiguous tensor, more tensors than the C ABI takes.  The moments live here, not in
         self.optimizer.state (the reference never saves optimizer state: policy/vdn.py:167-174)."""
         a = self.args
-        if not (self.device.type == 'cuda' and a.optimizer == 'ADAM' and getattr(a, 'fused_clip_adam', True)):
-            return False
         params = [p for p in self.eval_parameters if p.grad is not None]
-        if not params or len(params) > 32:
+        ok = (self.device.type == 'cuda' and a.optimizer == 'ADAM' and getattr(a, 'fused_clip_adam', True) and 0 < len(params) <= 32
+              and all(p.dtype == torch.float32 and p.grad.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+                      for p in params))
+        # the Adam moments live either here or in self.optimizer.state: a learner that changed sides mid-run would silently
+        # restart them, so the choice of the first step is binding
+        if getattr(self, '_fused_choice', None) is None:
+            self._fused_choice = ok
+        elif self._fused_choice != ok:
+            raise RuntimeError('VDN: the clip + Adam step changed from %s to %s between two learns (gradient layout / dtype / set of '
+                               'tensors changed); the two keep separate Adam moments' % (('torch', 'fused')[self._fused_choice], ('torch', 'fused')[ok]))
+        if not ok:
             return False
-        for p in params:
-            if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
-                return False
         import ctypes as C
         from .. import _lib
         lib = _lib.vdn_ops()
@@ -463,15 +461,21 @@ class VDN:
                                     arr([st['v'][id(p)] for p in params]), numel, float(a.grad_norm_clip), float(group['lr']),
                                     float(b1), float(b2), float(group['eps']), 1.0 - b1 ** st['step'], 1.0 - b2 ** st['step'],
                                     C.c_void_p(st['partials'].data_ptr()), C.c_void_p(st['norm'].data_ptr()),
+                                    None if grad_div is None else C.c_void_p(grad_div.data_ptr()),
                                     C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != 0:
             raise RuntimeError('vdn_clip_adam_step failed: %d (hip %d)' % (rc, lib.vdn_last_hip_error()))
         self.last_grad_norm = st['norm'][0]
         return True
 
-    def _step_and_sync(self, loss, train_step):
-        """clip_grad_norm_, optimizer step, hard target sync every target_update_cycle learns (policy/vdn.py:125-132)."""
-        if not self._fused_step():
+    def _step_and_sync(self, loss, train_step, grad_div=None):
+        """clip_grad_norm_, optimizer step, hard target sync every target_update_cycle learns (policy/vdn.py:125-132).  grad_div
+        (device scalar): p.grad holds the gradient of the un-normalised loss and is divided by it first."""
+        if grad_div is not None:
+            grad_div = grad_div.reshape(1).to(torch.float32)
+        if not self._fused_step(grad_div):
+            if grad_div is not None:
+                torch._foreach_div_([p.grad for p in self.eval_parameters if p.grad is not None], grad_div.reshape(()))
             self.last_grad_norm = torch.nn.utils.clip_grad_norm_(self.eval_parameters, self.args.grad_norm_clip)
             self.optimizer.step()
         self.last_loss = loss.detach()

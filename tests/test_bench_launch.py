@@ -59,3 +59,28 @@ def test_gpus_2_real_workload_on_one_card():
     assert sum(rk['played']) == round(rec['config']['env_steps_per_round'] * rec['steps'])
     assert rk['allreduces_timed_per_rank'] == 2 * 1 and min(rk['allreduce_ms_per_learn']) > 0     # steps x train_time
     assert rec['gemm_solutions'].startswith(('tuned', 'library default', 'tuning to'))
+
+
+@pytest.mark.gpu
+def test_one_rank_over_rccl_reproduces_the_plain_run(tmp_path):
+    """The RCCL path with one rank (BENCH_FORCE_DIST=1: process group on the `nccl` backend, parameter broadcast, the flat
+    gradient all-reduce of every learn with the next sample queued behind it, the step count riding along): every learn's
+    all-reduce is timed, and -- the un-normalised gradients being divided by the (all-reduced) mask count inside the clip + Adam
+    kernel on both paths -- the weights after the run equal those of the plain run bit for bit."""
+    import torch
+    common = ['--steps', '2', '--warmup', '1', '--no_cpu_baseline', '--no_tiers', '--n_envs', '1024', '--batch_size', '128',
+              '--train_time', '3', '--buffer_size', '4096', '--roofline_envs', '16384', '--roofline_envs_cached', '0']
+    recs, weights = [], []
+    for name, env in (('dist', {'BENCH_FORCE_DIST': '1'}), ('plain', {})):
+        path = str(tmp_path / (name + '.pt'))
+        p = _run(common + ['--dump_weights', path], **env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        recs.append(_json_line(p.stdout))
+        weights.append(torch.load(path))
+    dist, plain = recs
+    assert dist['n_gpus'] == 1 and 'ranks' in dist and 'ranks' not in plain
+    assert dist['ranks']['allreduces_timed_per_rank'] == 2 * 3                 # steps x train_time
+    assert dist['ranks']['allreduce_ms_per_learn'][0] > 0
+    assert dist['config']['env_steps_per_round'] == plain['config']['env_steps_per_round']
+    for k in weights[0]:
+        assert torch.equal(weights[0][k], weights[1][k]), 'RCCL one-rank run and plain run differ in %s' % k

@@ -127,6 +127,6 @@ def test_vdn_ops_library_exports():
         assert hasattr(lib, n)
     # argument guards run on the host before anything touches the GPU
     assert lib.vdn_td_forward(None, None, None, None, None, None, None, 4, 3, 8, 2, 5, 0.99, None, None, None, None) == -1
-    assert lib.vdn_clip_adam_step(0, None, None, None, None, None, 10.0, 1e-3, 0.9, 0.99, 1e-8, 0.1, 0.01, None, None, None) == -1
-    assert lib.vdn_clip_adam_step(33, None, None, None, None, None, 10.0, 1e-3, 0.9, 0.99, 1e-8, 0.1, 0.01, None, None, None) == -1
+    assert lib.vdn_clip_adam_step(0, None, None, None, None, None, 10.0, 1e-3, 0.9, 0.99, 1e-8, 0.1, 0.01, None, None, None, None) == -1
+    assert lib.vdn_clip_adam_step(33, None, None, None, None, None, 10.0, 1e-3, 0.9, 0.99, 1e-8, 0.1, 0.01, None, None, None, None) == -1
     assert lib.vdn_td_backward(None, None, None, None, 4, 3, 8, 2, 5, None, None) == -1
