@@ -160,7 +160,8 @@ __device__ __forceinline__ int cell_x(uint32_t c) { return (int)(c & 0xffffu); }
 __device__ __forceinline__ int cell_y(uint32_t c) { return (int)(c >> 16); }
 
 template <int N>
-__device__ __forceinline__ void load_env(const DevPtrs &p, int E, int e, EnvR<N> &r) {
+__device__ __forceinline__ void load_env(const DevPtrs &p, int E, int e, EnvR<N> &r, bool want_rstep = true, bool want_rmap = true,
+                                         bool want_rep = false) {
     using R = Rec<N>;
 #pragma unroll
     for (int w = 0; w < R::NP; ++w) {
@@ -172,9 +173,9 @@ __device__ __forceinline__ void load_env(const DevPtrs &p, int E, int e, EnvR<N>
     uint32_t s = p.st[(size_t)R::W_STEP * E + e];
     r.step = s & 0xffff; r.flags = (s >> 16) & kFlagMask; r.ulen = s >> kUlenShift;
     r.cum = p.st[(size_t)R::W_CUM * E + e];
-    r.rstep = p.st[(size_t)R::W_RSTEP * E + e];
-    r.rep = p.st[(size_t)R::W_REP * E + e];
-    r.rmap = p.st[(size_t)R::W_RMAP * E + e];
+    r.rstep = want_rstep ? p.st[(size_t)R::W_RSTEP * E + e] : 0u;
+    r.rep = want_rep ? p.st[(size_t)R::W_REP * E + e] : 0u;
+    r.rmap = want_rmap ? p.st[(size_t)R::W_RMAP * E + e] : 0u;
 }
 
 // record word w of a packed-cell array: agent 2w in the low half, 2w+1 in the high half, each x | y << 8
@@ -184,8 +185,10 @@ template <int N> __device__ __forceinline__ uint32_t pack_pos(const uint32_t (&c
     return v;
 }
 
+// with_goal: the lane's episode ended and a new task was drawn (goals and rng_ep change only then); rng_map never changes in a
+// transition; with_rstep: see k_step
 template <int N>
-__device__ __forceinline__ void store_env(const DevPtrs &p, int E, int e, const EnvR<N> &r, bool with_goal) {
+__device__ __forceinline__ void store_env(const DevPtrs &p, int E, int e, const EnvR<N> &r, bool with_goal, bool with_rstep = true) {
     using R = Rec<N>;
 #pragma unroll
     for (int w = 0; w < R::NP; ++w) {
@@ -194,9 +197,8 @@ __device__ __forceinline__ void store_env(const DevPtrs &p, int E, int e, const 
     }
     p.st[(size_t)R::W_STEP * E + e] = (r.step & 0xffff) | (r.flags << 16) | (r.ulen << kUlenShift);
     p.st[(size_t)R::W_CUM * E + e] = r.cum;
-    p.st[(size_t)R::W_RSTEP * E + e] = r.rstep;
-    p.st[(size_t)R::W_REP * E + e] = r.rep;
-    p.st[(size_t)R::W_RMAP * E + e] = r.rmap;
+    if (with_rstep) p.st[(size_t)R::W_RSTEP * E + e] = r.rstep;
+    if (with_goal) p.st[(size_t)R::W_REP * E + e] = r.rep;
 }
 
 template <int N> __device__ __forceinline__ bool any_dup(const EnvR<N> &r) {
@@ -644,7 +646,11 @@ __global__ __launch_bounds__(kBlock, step_min_waves(N)) void k_step(DevCfg c, De
         EnvR<N> r;
         bool ended = false;
         int flush_len = 0, flush_kind = 0;
-        if (present) load_env<N>(p, E, e, r);
+        // The record words a transition does not need stay in HBM: rng_ep (tasks generated) is read -- and written back -- only by a
+        // lane whose episode ends in this launch; rng_map only where health is rebuilt from the degrade count; rng_step (transitions
+        // executed = the counter word of the move draws) only by handles with maps: without maps no draw is ever consumed
+        // (health is 1.0 everywhere, dmfb.py:335).  Three words in and out per chip-step less for configs A / D.
+        if (present) load_env<N>(p, E, e, r, MAPS, MAPS);
         if (present && !active) {  // episode over, not reset yet: report a finished env, touch nothing
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -683,6 +689,7 @@ __global__ __launch_bounds__(kBlock, step_min_waves(N)) void k_step(DevCfg c, De
 #endif
                 const uint32_t gen = c.b_degrade ? r.rmap - 1u : 0u;  // counter value the current maps were drawn with
                 mvm = 0;
+                uint32_t w[4] = {0u, 0u, 0u, 0u};  // one Philox4x32-10 serves TWO droplets' 53-bit draws: (w0 w1) and (w2 w3)
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
                     const int cell = cell_x(r.pos[i]) * c.L + cell_y(r.pos[i]);
@@ -699,9 +706,8 @@ __global__ __launch_bounds__(kBlock, step_min_waves(N)) void k_step(DevCfg c, De
 #ifdef DMFB_ABLATE_PHILOX
                         draw = (double)((r.rstep * 2654435761u + (uint32_t)i * 40503u) >> 8) * (1.0 / 16777216.0);
 #else
-                        uint32_t w[4];
-                        philox(c.k0, c.k1, c.env_id0 + (uint32_t)e, r.rstep, (uint32_t)i, STREAM_MOVE << 8, w);
-                        draw = u53(w[0], w[1]);
+                        if ((i & 1) == 0) philox(c.k0, c.k1, c.env_id0 + (uint32_t)e, r.rstep, (uint32_t)(i >> 1), STREAM_MOVE << 8, w);
+                        draw = (i & 1) ? u53(w[2], w[3]) : u53(w[0], w[1]);
 #endif
                     }
                     mvm |= (uint32_t)(draw <= prob) << i;
@@ -878,6 +884,7 @@ __global__ __launch_bounds__(kBlock, step_min_waves(N)) void k_step(DevCfg c, De
             }
         }
         // ---- episode boundary inside the launch: reset(new=False) for the lanes that ended
+        if (ended) r.rep = p.st[(size_t)Rec<N>::W_REP * E + e];
         unsigned long long m = __ballot(ended);
         while (m) {
             const int src = __ffsll((long long)m) - 1;
@@ -896,7 +903,7 @@ __global__ __launch_bounds__(kBlock, step_min_waves(N)) void k_step(DevCfg c, De
                 r.rep += 1; r.step = 0; r.cum = 0; r.flags = 0;
             }
         }
-        if (active) store_env<N>(p, E, e, r, ended);
+        if (active) store_env<N>(p, E, e, r, ended, MAPS);
 
         if (present) {
             if (want_obs) {
@@ -1102,6 +1109,7 @@ __global__ __launch_bounds__(kBlock) void k_reset(DevCfg c, DevPtrs p, const uin
         r.rep = rep + 1;
         r.rmap = rmap + ((mode == 1 || mode == 3) && p.health && c.b_degrade ? 1u : 0u);
         store_env<N>(p, E, e, r, true);
+        p.st[(size_t)R::W_RMAP * E + e] = r.rmap;   // (store_env leaves rng_map alone: a transition never changes it)
     }
     if (p.health) {
         if (mode == 0) {  // refresh(new=False): the episode's usage, then updateHealth (dmfb.py:182-183)

@@ -160,8 +160,8 @@ __global__ __launch_bounds__(kBlock) void k_step_lanes(DevCfg c, DevPtrs p, Step
         if (a.uniforms) draw = a.uniforms[(size_t)e * N + i];
         else {
             uint32_t w[4];
-            philox(c.k0, c.k1, c.env_id0 + (uint32_t)e, r.rstep, (uint32_t)i, STREAM_MOVE << 8, w);
-            draw = u53(w[0], w[1]);
+            philox(c.k0, c.k1, c.env_id0 + (uint32_t)e, r.rstep, (uint32_t)(i >> 1), STREAM_MOVE << 8, w);   // droplets 2p, 2p + 1 share a block
+            draw = (i & 1) ? u53(w[2], w[3]) : u53(w[0], w[1]);
         }
         if (compact) {
             const int k = kmap_get(p, kmap_bytes(cells), e, cell);

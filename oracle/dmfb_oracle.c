@@ -461,9 +461,9 @@ static int step_env(dmfb_oracle *o, dmfb_env *e, const int32_t *actions, const d
         double u;
         if (uniforms) u = uniforms[i];
         else {
-            uint32_t w[4];
-            env_philox(o, e, e->rng_step, (uint32_t)i, STREAM_MOVE, 0, w);
-            u = u53(w[0], w[1]);
+            uint32_t w[4]; /* RNG contract: droplets 2p and 2p + 1 share one Philox block, words (0 1) and (2 3) */
+            env_philox(o, e, e->rng_step, (uint32_t)(i >> 1), STREAM_MOVE, 0, w);
+            u = (i & 1) ? u53(w[2], w[3]) : u53(w[0], w[1]);
         }
         int rc = move_one(o, e, i, actions[i], u, &rewards[i], &pastx[i], &pasty[i]);
         if (rc) return rc;

@@ -121,7 +121,7 @@ if __name__ == '__main__':
     for name in a.cfg.split(','):
         sizes = a.msizes if (name.startswith('M') and a.msizes) else a.sizes
         for E in [int(s) for s in sizes.split(',')]:
-            if name != 'A' and E > 262144 or name.startswith('M') and E > 65536:
+            if name != 'A' and E > 262144 or name.startswith("M") and E > 163840:
                 continue
             print(json.dumps(run(name, E, a.iters, observe=a.observe, labels=labels)), flush=True)
     if a.labels:
