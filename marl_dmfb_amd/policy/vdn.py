@@ -131,7 +131,8 @@ class _TDLossPacked(torch.autograd.Function):
         return (gq,) + (None,) * 12
 
 
-PACK_ROWS = 2048  # packed row counts are rounded up to a multiple of this (zero rows): few distinct GEMM shapes, split-K friendly
+PACK_ROWS = 2048  # packed row counts of 32 768 rows and more (where the split-K weight gradients apply) are rounded up to a multiple
+                  # of this (zero rows): few distinct GEMM shapes, every one divisible by the 64 split-K chunks; smaller ones to 64
 
 
 class VDN:
@@ -337,8 +338,8 @@ class VDN:
         return self._step_and_sync(num.detach() / total, train_step, grad_div=total)
 
     def packed_ok(self, buffers):
-        """learn_packed applies to the replay ring on the GPU (int8 / float32 / bool episode tensors), the fov-9 CRNN with the HIP
-        front end and GRU sequence kernels, and the parameter-free VDN mixer."""
+        """learn_packed applies to the replay ring on the GPU (int8 / float32 / bool episode tensors), the CRNN with one of the two
+        HIP front ends (fov 9; fov 19 = MEDA) and the GRU sequence kernels, and the parameter-free VDN mixer."""
         import ctypes  # noqa: F401
         net = self.eval_rnn
         o = buffers.get('o')
@@ -352,7 +353,8 @@ class VDN:
             return False
         probe = o.view(-1, o.shape[-1])[:1]
         with torch.no_grad():
-            return bool(hasattr(net, '_hip_conv_ok') and net._hip_conv_ok(probe) and net._hip_geometry() == 9)
+            return bool(hasattr(net, '_hip_conv_ok') and net._hip_conv_ok(probe) and net._hip_geometry() in (9, 19)
+                        and hasattr(net, '_hip_train_ok'))
 
     @staticmethod
     def pack_units(idx, lens, t_ring):
@@ -381,7 +383,8 @@ class VDN:
             counts, units = plan
         U = int(units.shape[0])
         V = U * n
-        Vp = -(-V // PACK_ROWS) * PACK_ROWS
+        pad = PACK_ROWS if V >= 32768 else 64
+        Vp = -(-V // pad) * pad
         import ctypes as C
         from .. import _lib
         lib = _lib.vdn_ops()

@@ -42,7 +42,7 @@ def test_learn_with_host_length_bound_matches_reference_gpu(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('path', [f for f in FILES if 'meda' not in os.path.basename(f)], ids=os.path.basename)
+@pytest.mark.parametrize('path', FILES, ids=os.path.basename)
 def test_learn_packed_matches_reference_gpu(path):
     """VDN.learn_packed (what Trainer runs in continuous mode): conv front end, GRU input projection and head on the valid
     (episode, step) rows only, GRU sequence kernels that stop every row at its own length, TD block indexing the replay tensors
