@@ -79,6 +79,11 @@ typedef struct {
     int8_t *d_obs;          /* [E][n][3*fov*fov+2] observation after the step            dmfb.py:576 */
     double *d_team_reward;  /* [E]    np.sum(rewards)/n in numpy's pairwise order        common/rollout.py:33 */
     uint8_t *d_terminated;  /* [E]    all(dones)                                         common/rollout.py:34-35 */
+    int8_t *d_obs_terminal; /* [E][n][3*fov*fov+2] or NULL.  With DMFB_STEP_AUTORESET the d_obs row of an env whose episode ended is
+                               the FIRST observation of its next episode; the observation the reference returns for that step (the
+                               terminal one, `o_next` of the episode's last transition, common/rollout.py:38,118) is written here --
+                               rows of envs that did not end in this call are left untouched.  Fused launch only (n_envs below
+                               dmfb_vec_launch_shape()[2]); DMFB_ERR_UNSUPPORTED otherwise. */
 } dmfb_vec_step_out;
 
 /* The guards of DMFBenv.__init__ / RoutingTaskManager.__init__ (dmfb.py:489-490, 139-146). */

@@ -146,9 +146,12 @@ int rollout_gru_head_select_stream(const float *d_igates, const float *d_hgates,
  * parity 0 reads ring->d_state and writes stage->d_state_alt, parity 1 the other way round; the caller alternates and, after an odd
  * number of calls, copies d_state_alt back.  The caller then resets the closed chips' env (dmfb_vec_reset / meda_vec_reset with
  * d_term as mask), which also rewrites their rows of d_obs_new with the first observation of the next episode.
+ * d_obs_term (may be NULL): when the env resets ended chips INSIDE its transition launch (DMFB_STEP_AUTORESET with
+ * dmfb_vec_step_out::d_obs_terminal) d_obs_new already holds an ended chip's next first observation and its terminal observation
+ * is taken from d_obs_term[e] instead; no reset call follows then.
  * obs_row_bytes = n_agents * observation bytes. */
 int rollout_stream_step(int32_t n_envs, int32_t n_agents, int32_t n_actions, int32_t episode_limit, int32_t obs_row_bytes,
-                        int32_t hidden, const int8_t *d_obs_prev, const int8_t *d_obs_new, const uint8_t *d_term,
+                        int32_t hidden, const int8_t *d_obs_prev, const int8_t *d_obs_new, const int8_t *d_obs_term, const uint8_t *d_term,
                         const double *d_team_reward, const void *d_constraints, int32_t constraints_f64, const uint8_t *d_success,
                         const rollout_stage *stage, const rollout_ring *ring, int32_t parity, float *d_hidden, int8_t *d_last_onehot,
                         float *d_epsilon, float anneal, float min_epsilon, uint32_t *d_draw, void *stream);

@@ -16,7 +16,8 @@ class HipLibraryMissing(RuntimeError):
 def load(name):
     if name in _CACHE:
         return _CACHE[name]
-    path = os.path.join(LIB_DIR, 'lib%s.so' % name)
+    # MARL_DMFB_VARIANT_<NAME>=_tag loads lib<name>_tag.so instead: same-box A/B timing of a kernel variant (development aid)
+    path = os.path.join(LIB_DIR, 'lib%s%s.so' % (name, os.environ.get('MARL_DMFB_VARIANT_' + name.upper(), '')))
     if not os.path.exists(path):
         raise HipLibraryMissing(
             '%s not found: build the HIP extension first (python -c "import __graft_entry__ as g; g.build()" '
@@ -42,7 +43,7 @@ class DmfbVecStepOut(C.Structure):
     """include/dmfb_vec.h: dmfb_vec_step_out"""
     _fields_ = [('d_rewards', C.c_void_p), ('d_dones', C.c_void_p), ('d_constraints', C.c_void_p),
                 ('d_success', C.c_void_p), ('d_obs', C.c_void_p), ('d_team_reward', C.c_void_p),
-                ('d_terminated', C.c_void_p)]
+                ('d_terminated', C.c_void_p), ('d_obs_terminal', C.c_void_p)]
 
 
 DMFB_VEC_SYMBOLS = [
@@ -197,7 +198,7 @@ def rollout_ops():
     lib.rollout_post_step.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, i32, vp, vp, vp]
     lib.rollout_gru_head_select_stream.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, u64, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     ringp, stagep = C.POINTER(RolloutRing), C.POINTER(RolloutStage)
-    lib.rollout_stream_step.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, stagep, ringp, i32, vp, vp, vp, f32, f32, vp, vp]
+    lib.rollout_stream_step.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, stagep, ringp, i32, vp, vp, vp, f32, f32, vp, vp]
     lib.rollout_last_hip_error.argtypes = []
     lib._typed = True
     return lib

@@ -298,11 +298,18 @@ class RolloutWorker(Evaluator):
         # the observation is double-buffered: the transition of lock-step s reads obs[s & 1] (through the Q-network) and writes
         # obs[(s + 1) & 1], so that the first observation of an episode is still there when its first step is staged
         st.obs = [z((E, n, O), torch.int8), z((E, n, O), torch.int8)]
+        # Reset inside the transition launch where the env offers the terminal observation as a second output (DMFB fused
+        # launch, include/dmfb_vec.h: d_obs_terminal): two launches per lock-step less than step + reset + observe
+        st.fused_reset = bool(getattr(self, 'stream_fused_reset', True) and hasattr(self.env._out, 'd_obs_terminal')
+                              and hasattr(self.env, 'launch_shape') and E < self.env.launch_shape().get('split_min_envs', 0))
+        st.obs_term = z((E, n, O), torch.int8) if st.fused_reset else None
         st.out = []
         for k in range(2):
             o = type(self.env._out)()
             C.memmove(C.byref(o), C.byref(self.env._out), C.sizeof(o))
             o.d_obs = st.obs[k].data_ptr()
+            if st.fused_reset:
+                o.d_obs_terminal = st.obs_term.data_ptr()
             st.out.append(o)
         st.hidden = z((E * n, self.agents.args.rnn_hidden_dim), torch.float32)
         st.last_action = z((E, n, A), torch.int8)
@@ -363,11 +370,11 @@ class RolloutWorker(Evaluator):
             if rc != 0:
                 raise RuntimeError('rollout_gru_head_select_stream failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
             u = self.uniforms_fn(s) if self.uniforms_fn is not None else None
-            _, _, _, info = env.step(st.actions, uniforms=u, record=True, out=st.out[(s + 1) & 1])
+            _, _, _, info = env.step(st.actions, uniforms=u, record=True, autoreset=st.fused_reset, out=st.out[(s + 1) & 1])
             cons = info['constraints']
             cons_f64 = int(cons.dtype == torch.float64)
             rc = lib.rollout_stream_step(E, n, A, T, n * env.obs_len, st.hidden.shape[1], vp(cur.data_ptr()), vp(nxt.data_ptr()),
-                                         vp(info['terminated'].data_ptr()), vp(info['team_reward'].data_ptr()), vp(cons.data_ptr()),
+                                         vp(st.obs_term.data_ptr()) if st.fused_reset else None, vp(info['terminated'].data_ptr()), vp(info['team_reward'].data_ptr()), vp(cons.data_ptr()),
                                          cons_f64, vp(info['success'].data_ptr()), C.byref(st.stage), C.byref(st.ring), s & 1,
                                          vp(st.hidden.data_ptr()), vp(st.last_action.data_ptr()), vp(st.eps.data_ptr()), anneal,
                                          float(self.min_epsilon), vp(self._draw.data_ptr()), stream)
@@ -375,7 +382,8 @@ class RolloutWorker(Evaluator):
                 raise RuntimeError('rollout_stream_step failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
             if self.stream_step_hook is not None:   # tests: (lock-step, actions, terminated) before the chips are reset
                 self.stream_step_hook(s, st.actions, info['terminated'])
-            env.reset(mask=info['terminated'], obs=nxt)   # reset(new=False) of the chips whose episode ended (rollout.py:103)
+            if not st.fused_reset:
+                env.reset(mask=info['terminated'], obs=nxt)   # reset(new=False) of the chips whose episode ended (rollout.py:103)
         if K & 1:   # the double-buffered observation and ring state end in their second buffers
             st.obs[0].copy_(st.obs[1])
             st.buffer.ring_state.copy_(st.state_alt)

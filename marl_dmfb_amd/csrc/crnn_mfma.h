@@ -38,8 +38,19 @@ template <int OD, int RBV = 0, int NW = 8> struct GeoM {
     static constexpr int RB = RBV ? RBV : (OD <= 24 ? 16 : 12);  // rows per iteration (LDS-bound)
     static constexpr int CS = 53;                        // conv1 activation stride per channel: odd, so the epilogue's
                                                          // 16 channel lanes fall on different banks
-    static constexpr int ROW_A1 = OD * CS;
-    static constexpr int IN_STRIDE = 244;
+    // ROWLANE (a block of exactly 16 rows: od 24): the 16 M entries of an MFMA tile are the 16 ROWS of the block at ONE output
+    // position, instead of 16 consecutive (row, position) pairs.  Lane (j, kq) of the A operand then reads
+    // row j * ROW_STRIDE + kq * (odd channel / tap offset) + a wave-uniform position offset: with the row strides = 2 (mod 32
+    // words) the 32 lanes of a ds_read_b32 group (j = 0..15, two kq) hit 32 different banks.  With 16 consecutive positions of one
+    // row as the tile (the other geometry) the two kq halves overlap on 6 of 16 banks: 4 LDS cycles per gather instead of 2
+    // (SQ_LDS_BANK_CONFLICT = 44 % of the LDS cycles, profiles/r03/pmc_conv_summary.json).
+#ifdef CRNN_NO_ROWLANE   // same-box A/B builds only (tools/ab_conv.sh)
+    static constexpr bool ROWLANE = false;
+#else
+    static constexpr bool ROWLANE = RB == 16;
+#endif
+    static constexpr int ROW_A1 = ROWLANE ? (OD * CS + 31) / 32 * 32 + 2 : OD * CS;
+    static constexpr int IN_STRIDE = ROWLANE ? 258 : 244;
     static constexpr int PAD_COLS = (OD * 25 + 10 + 63) / 64 * 64;  // 640 / 832: a row may be written out zero-padded to a
                                                          // multiple of 64 floats (the GRU input GEMM runs 15-25 % faster on K = 640 than on 610)
     static constexpr int OUT_STRIDE = PAD_COLS + 4;      // staged output row: conv features | 10 vector features | zeros
@@ -67,9 +78,16 @@ __device__ __forceinline__ void conv2_tiles(const float *s_a1, float *s_out, con
     f32x4 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        int m = (n == 0 ? t0 : t1) * 16 + j;
-        m = m < G::M2 ? m : G::M2 - 1;
-        const int r = m / 25, p = m - r * 25;
+        int r, p;
+        if constexpr (G::ROWLANE) {   // tile = output position, lane j = row j
+            r = j;
+            p = n == 0 ? t0 : t1;
+        } else {
+            int m = (n == 0 ? t0 : t1) * 16 + j;
+            m = m < G::M2 ? m : G::M2 - 1;
+            r = m / 25;
+            p = m - r * 25;
+        }
         ap[n] = s_a1 + r * G::ROW_A1 + (p / 5) * 7 + p % 5 + kq * G::CS;
         acc[n] = f32x4{bias2, bias2, bias2, bias2};
     }
@@ -109,8 +127,12 @@ __device__ __forceinline__ void conv2_tiles(const float *s_a1, float *s_out, con
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int mm = (n == 0 ? t0 : t1) * 16 + kq * 4 + q;
-                if (mm < G::M2) { const int rr = mm / 25, pp = mm - rr * 25; s_out[rr * G::OUT_STRIDE + ch * 25 + pp] = fmaxf(acc[n][q], 0.0f); }
+                if constexpr (G::ROWLANE) {   // D row 4 kq + q = block row, the tile's position is the column inside the channel
+                    s_out[(kq * 4 + q) * G::OUT_STRIDE + ch * 25 + (n == 0 ? t0 : t1)] = fmaxf(acc[n][q], 0.0f);
+                } else {
+                    const int mm = (n == 0 ? t0 : t1) * 16 + kq * 4 + q;
+                    if (mm < G::M2) { const int rr = mm / 25, pp = mm - rr * 25; s_out[rr * G::OUT_STRIDE + ch * 25 + pp] = fmaxf(acc[n][q], 0.0f); }
+                }
             }
     }
 }
@@ -227,7 +249,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv9_mfma(const int8_t *__restrict
         const bool kv = k < 27;
         bw1[s] = (chv && kv) ? s_in[ch * 27 + k] : 0.0f;
         const int c0 = k / 9, tap = k - c0 * 9;
-        off1[s] = kv ? c0 * 81 + (tap / 3) * 9 + tap % 3 : 0;
+        off1[s] = kv ? c0 * 81 + (tap / 3) * 9 + tap % 3 : (G::ROWLANE ? 1 : 0);   // (k = 27: zero weight; an odd offset keeps its bank apart from k = 26's)
     }
     int goff[3];
 #pragma unroll
@@ -272,7 +294,71 @@ __global__ __launch_bounds__(64 * NW) void k_conv9_mfma(const int8_t *__restrict
         CRNN_TS(1);
         // ---- conv1
 #ifndef CRNN_PROBE_SKIP_CONV1
-        {
+        if constexpr (G::ROWLANE) {
+            // Tile = ONE of the 49 conv1 output positions for the 16 rows of the block (lane j = row j); wave `sub` of a channel half
+            // takes positions sub, sub + 4, ...: 13 or 12 tiles, three accumulator chains at a time, the gathers of the next three
+            // in flight while the MFMAs of the current three issue.  Address = lane part (row, k) + wave-uniform position offset.
+            constexpr int NT1 = 49, NIT = (NT1 / G::NSUB) / 3;   // 12 tiles per wave in 4 passes of 3; position 48 is wave 0's 13th
+            static_assert(G::NSUB == 4 && NIT * 3 * G::NSUB == NT1 - 1, "conv1 row-lane tiling");
+            const int sub_u = __builtin_amdgcn_readfirstlane(sub);
+            int jb = j * G::IN_STRIDE;
+            asm volatile("" : "+v"(jb));   // formed per block: hoisted out of the block loop the seven addresses stay live through conv2
+            int lb[7];
+#pragma unroll
+            for (int s = 0; s < 7; ++s) lb[s] = jb + off1[s];
+            auto spos = [&](int m) {  // offset of position sub + 4 m in the 9x9 image
+                const int p = sub_u + G::NSUB * m;
+                return (p / 7) * 9 + p % 7;
+            };
+            float cv[2][3][7];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int sp = spos(c);
+#pragma unroll
+                for (int s = 0; s < 7; ++s) cv[0][c][s] = s_in[lb[s] + sp];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (it + 1 < NIT) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int sp = spos(3 * (it + 1) + c);
+#pragma unroll
+                        for (int s = 0; s < 7; ++s) cv[(it + 1) & 1][c][s] = s_in[lb[s] + sp];
+                    }
+                } else if (sub_u == 0) {   // the gathers of position 48 (image offset 60), wave 0 of each channel half
+#pragma unroll
+                    for (int s = 0; s < 7; ++s) cv[(it + 1) & 1][0][s] = s_in[lb[s] + 60];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 acc[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = f32x4{bias1, bias1, bias1, bias1};
+#pragma unroll
+                for (int s = 0; s < 7; ++s)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[it & 1][c][s], bw1[s], acc[c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (chv) {   // D row 4 kq + q = block row
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float *dst = s_a1 + kq * 4 * G::ROW_A1 + ch * G::CS + sub_u + G::NSUB * (3 * it + c);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dst[q * G::ROW_A1] = fmaxf(acc[c][q], 0.0f);
+                    }
+                }
+            }
+            if (sub_u == 0) {
+                f32x4 acc = {bias1, bias1, bias1, bias1};
+#pragma unroll
+                for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[NIT & 1][0][s], bw1[s], acc, 0, 0, 0);
+                if (chv) {
+                    float *dst = s_a1 + kq * 4 * G::ROW_A1 + ch * G::CS + 48;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dst[q * G::ROW_A1] = fmaxf(acc[q], 0.0f);
+                }
+            }
+        } else {
             // Tiles follow the rows so that no index needs a division: a row's positions 0..47 are three tiles
             // (quarter qt: p = 16 qt + i), position 48 of all RB rows is one more tile.  Wave `sub` takes rows
             // sub, sub + 4, ...: three accumulator chains per row; the gathers of the next row are in flight while

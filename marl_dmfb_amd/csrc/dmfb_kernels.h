@@ -634,10 +634,29 @@ __global__ __launch_bounds__(kBlock, step_min_waves(N)) void k_step(DevCfg c, De
     // obs tile meanwhile.
     const int step_waves = (T + kWave - 1) / kWave;
 
+    // Terminal observations (dmfb_vec_step_out::d_obs_terminal): with the reset inside the launch the observation phases below show
+    // an ended chip's NEXT episode; the observation the reference hands back for the ending step is built first, from the cells
+    // the droplets ended on and the obstacle blocks of the ending episode, and only the ended chips' rows of it are written.
+    // Every wave calls this at its own place in the code (the stepping wave between the transition and the reset, the others
+    // behind the zero-fill): the same sequence of workgroup barriers on every path.  A tile without an ended chip pays one barrier.
+    const bool term_obs = OBS && a.out.d_obs_terminal != nullptr;
+    auto terminal_pass = [&](bool mine_ended) {
+        if (!__syncthreads_or((int)mine_ended)) return;   // (also publishes the zeroed tile, the tables and the stepping wave's cells)
+        scatter_bands<N>(c, t, smem, tv, tid, kBlock);
+        __syncthreads();
+        scatter_rows<N>(c, p, t, tile_base, tv, tid, kBlock);
+        __syncthreads();
+        const int row_bytes = N * c.obs_len;
+        for (int b = tid; b < tv * row_bytes; b += kBlock)
+            if (t.flag[b / row_bytes]) a.out.d_obs_terminal[(size_t)tile_base * row_bytes + b] = t.obs[b];
+        __syncthreads();
+        zero_tile(smem, (int)(align16((size_t)shift + (size_t)tv * N * c.obs_len) >> 4), tid, kBlock);   // for the phases below
+    };
     if (wave >= step_waves) {
         if (want_obs) load_tables(c, p, t, tid - step_waves * kWave, kBlock - step_waves * kWave);
         if (want_obs) zero_tile(smem, (int)(align16((size_t)shift + (size_t)tv * N * c.obs_len) >> 4), tid - step_waves * kWave,
                                 kBlock - step_waves * kWave);
+        if (term_obs) terminal_pass(false);
     } else {
         const int slot = tid;
         const bool present = slot < tv;
@@ -882,6 +901,17 @@ __global__ __launch_bounds__(kBlock, step_min_waves(N)) void k_step(DevCfg c, De
                 flush_kind = ended ? 1 : 2;  // 1: + updateHealth (reset(new=False), dmfb.py:182-183)   2: log full
                 r.ulen = 0;
             }
+        }
+        if (term_obs) {  // the cells the step ended on, flag = "this chip's episode ended"; both are rewritten after the reset
+            if (present) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    t.pos[slot * N + i] = r.pos[i];
+                    t.goal[slot * N + i] = r.goal[i];
+                }
+                t.flag[slot] = (uint8_t)ended;
+            }
+            terminal_pass(ended);
         }
         // ---- episode boundary inside the launch: reset(new=False) for the lanes that ended
         if (ended) r.rep = p.st[(size_t)Rec<N>::W_REP * E + e];

@@ -255,6 +255,7 @@ template <int N> int step_only_n(dmfb_vec *h, const StepArgs &b, hipStream_t s) 
 
 template <int N> int step_n(dmfb_vec *h, const StepArgs &a, hipStream_t s) {
     const int E = h->cfg.n_envs;
+    if (a.out.d_obs_terminal && (!a.out.d_obs || E >= h->split_min || !(a.flags & DMFB_STEP_AUTORESET))) return DMFB_ERR_UNSUPPORTED;
     if (a.out.d_obs && E >= h->split_min) {
         StepArgs b = a;
         b.out.d_obs = nullptr;

@@ -254,7 +254,7 @@ __device__ __forceinline__ int nz_bytes(uint32_t w) { return __popc((w | ((w & 0
 constexpr int kStreamBlock = 256;  // (1024 threads move a closing episode faster -- 50 vs 82 us for 60 MEDA steps -- but make every launch without a close 10 us slower)
 template <typename V>
 __global__ __launch_bounds__(kStreamBlock) void k_stream_step(int E, int n, int A, int T, int S, int row_v, int H, const V *__restrict__ obs_prev,
-                                                     const V *__restrict__ obs_new, const uint8_t *__restrict__ term,
+                                                     const V *__restrict__ obs_new, const V *__restrict__ obs_term, const uint8_t *__restrict__ term,
                                                      const double *__restrict__ team_reward, const void *__restrict__ constraints, int cons_f64,
                                                      const uint8_t *__restrict__ success, int32_t *__restrict__ t_ep, V *__restrict__ stage_o0,
                                                      V *__restrict__ stage_o_next, const int8_t *__restrict__ stage_u,
@@ -267,7 +267,9 @@ __global__ __launch_bounds__(kStreamBlock) void k_stream_step(int E, int n, int 
     const int e = blockIdx.x, tid = threadIdx.x;
     const int t = t_ep[e];
     const bool tm = term[e] != 0;
-    const V *on = obs_new + (size_t)e * row_v, *op = obs_prev + (size_t)e * row_v;
+    // the observation after this step: with the env's reset inside the transition launch obs_new already shows an ended chip's
+    // NEXT episode and the terminal observation comes in obs_term (dmfb_vec.h: d_obs_terminal)
+    const V *on = (tm && obs_term ? obs_term : obs_new) + (size_t)e * row_v, *op = obs_prev + (size_t)e * row_v;
     V *so = stage_o_next + (size_t)e * T * row_v;
     for (int k = tid; k < row_v; k += kStreamBlock) {
         so[(size_t)t * row_v + k] = on[k];
@@ -501,7 +503,7 @@ int rollout_gru_head_select_stream(const float *d_igates, const float *d_hgates,
 }
 
 int rollout_stream_step(int32_t n_envs, int32_t n_agents, int32_t n_actions, int32_t episode_limit, int32_t obs_row_bytes,
-                        int32_t hidden, const int8_t *d_obs_prev, const int8_t *d_obs_new, const uint8_t *d_term,
+                        int32_t hidden, const int8_t *d_obs_prev, const int8_t *d_obs_new, const int8_t *d_obs_term, const uint8_t *d_term,
                         const double *d_team_reward, const void *d_constraints, int32_t constraints_f64, const uint8_t *d_success,
                         const rollout_stage *stage, const rollout_ring *ring, int32_t parity, float *d_hidden, int8_t *d_last_onehot,
                         float *d_epsilon, float anneal, float min_epsilon, uint32_t *d_draw, void *stream) {
@@ -518,17 +520,17 @@ int rollout_stream_step(int32_t n_envs, int32_t n_agents, int32_t n_actions, int
     const int64_t *st_in = parity ? stage->d_state_alt : ring->d_state;
     int64_t *st_out = parity ? ring->d_state : stage->d_state_alt;
     const bool dw = obs_row_bytes % 4 == 0 &&
-                    ((size_t)d_obs_prev | (size_t)d_obs_new | (size_t)stage->d_o0 | (size_t)stage->d_o_next | (size_t)ring->d_o | (size_t)ring->d_o_next) % 4 == 0;
+                    ((size_t)d_obs_prev | (size_t)d_obs_new | (size_t)d_obs_term | (size_t)stage->d_o0 | (size_t)stage->d_o_next | (size_t)ring->d_o | (size_t)ring->d_o_next) % 4 == 0;
     (void)hipGetLastError();
     if (dw)
         hipLaunchKernelGGL((k_stream_step<uint32_t>), dim3((unsigned)n_envs), dim3(kStreamBlock), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
                            episode_limit, ring->slots, obs_row_bytes / 4, hidden, (const uint32_t *)d_obs_prev, (const uint32_t *)d_obs_new,
-                           d_term, d_team_reward, d_constraints, constraints_f64, d_success, stage->d_t_ep, (uint32_t *)stage->d_o0,
+                           (const uint32_t *)d_obs_term, d_term, d_team_reward, d_constraints, constraints_f64, d_success, stage->d_t_ep, (uint32_t *)stage->d_o0,
                            (uint32_t *)stage->d_o_next, stage->d_u, stage->d_onehot, stage->d_r, stage->d_ep_acc, stage->d_chip_acc,
                            stage->d_close_slot, rp, st_in, st_out, d_hidden, d_last_onehot, d_epsilon, anneal, min_epsilon, d_draw);
     else
         hipLaunchKernelGGL((k_stream_step<int8_t>), dim3((unsigned)n_envs), dim3(kStreamBlock), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
-                           episode_limit, ring->slots, obs_row_bytes, hidden, d_obs_prev, d_obs_new, d_term, d_team_reward, d_constraints,
+                           episode_limit, ring->slots, obs_row_bytes, hidden, d_obs_prev, d_obs_new, d_obs_term, d_term, d_team_reward, d_constraints,
                            constraints_f64, d_success, stage->d_t_ep, stage->d_o0, stage->d_o_next, stage->d_u, stage->d_onehot, stage->d_r,
                            stage->d_ep_acc, stage->d_chip_acc, stage->d_close_slot, rp, st_in, st_out, d_hidden, d_last_onehot, d_epsilon,
                            anneal, min_epsilon, d_draw);

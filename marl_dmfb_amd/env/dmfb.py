@@ -85,7 +85,7 @@ class VecDMFB:
         self.terminated = torch.zeros((E,), dtype=torch.uint8, device=dev)
         self._out = _lib.DmfbVecStepOut(self.rewards.data_ptr(), self.dones.data_ptr(), self.constraints.data_ptr(),
                                         self.success.data_ptr(), self.obs.data_ptr(), self.team_reward.data_ptr(),
-                                        self.terminated.data_ptr())
+                                        self.terminated.data_ptr(), None)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

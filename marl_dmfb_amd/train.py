@@ -74,7 +74,9 @@ class Trainer:
         draws = [self.buffer.draw(k_batch) for _ in range(learns)]   # host RNG: the order of the draws is fixed here
         prefetched = []
         if self._packed is None:
-            self._packed = bool(getattr(self.args, 'packed_learn', True) and hasattr(pol, 'packed_ok') and pol.packed_ok(self.buffer.buffers))
+            want = getattr(self.args, 'packed_learn', None)
+            want = (os.environ.get('MARL_DMFB_PACKED_LEARN', '1') != '0') if want is None else bool(want)   # (env var: A/B timing)
+            self._packed = bool(want and hasattr(pol, 'packed_ok') and pol.packed_ok(self.buffer.buffers))
         plans = self._upload_plans(draws) if (self._packed and learns) else None
         for k in range(learns):
             idx, lens = draws[k]

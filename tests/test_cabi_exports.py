@@ -107,7 +107,7 @@ def test_rollout_ops_library_exports():
     names = sorted(set(re.findall(r'\b(rollout_[a-z_0-9]+)\s*\(', txt)))
     assert names == ['rollout_compact_alive', 'rollout_gru_head_select', 'rollout_gru_head_select_live', 'rollout_gru_head_select_stream',
                      'rollout_last_hip_error', 'rollout_post_step', 'rollout_select_actions', 'rollout_stream_step']
-    assert lib.rollout_stream_step(4, 2, 5, 10, 490, 128, None, None, None, None, None, 0, None, None, None, 0, None, None, None, 0.0, 0.0, None, None) == -1
+    assert lib.rollout_stream_step(4, 2, 5, 10, 490, 128, None, None, None, None, None, None, 0, None, None, None, 0, None, None, None, 0.0, 0.0, None, None) == -1
     assert lib.rollout_compact_alive(4, None, None, None, None) == -1
     for n in names:
         assert hasattr(lib, n)
