@@ -234,7 +234,7 @@ def loop_breakdown_stream(trainer, rounds):
         for _ in range(a.train_time):
             idx, lens = buf.draw(min(buf.current_size, a.batch_size))
             if trainer._packed:
-                trainer.agents.policy.learn_packed(buf.buffers, idx, lens, trainer.trained_times, plan=trainer._upload_plans([(idx, lens)])[0])
+                trainer.agents.policy.learn_packed(buf.buffers, idx, lens, trainer.trained_times)
             else:
                 trainer.agents.train(buf.gather(idx), trainer.trained_times, max_len=int(lens[0]))
             trainer.trained_times += 1

@@ -77,11 +77,13 @@ class Trainer:
             want = getattr(self.args, 'packed_learn', None)
             want = (os.environ.get('MARL_DMFB_PACKED_LEARN', '1') != '0') if want is None else bool(want)   # (env var: A/B timing)
             self._packed = bool(want and hasattr(pol, 'packed_ok') and pol.packed_ok(self.buffer.buffers))
-        plans = self._upload_plans(draws) if (self._packed and learns) else None
         for k in range(learns):
             idx, lens = draws[k]
             if self._packed:   # the padded steps of the drawn episodes are never computed; the ring is read in place
-                pol.learn_packed(self.buffer.buffers, idx, lens, self.trained_times, plan=plans[k])
+                # (its unit list is packed and uploaded inside, one small pageable copy per learn: measured faster than one upload of the
+                # round's lists up front, which leaves the GPU idle for the packing of all of them, and much faster than a persistent
+                # pinned staging buffer, which made later HIP calls of the round stall for tens of milliseconds -- tools/dbg_round.py)
+                pol.learn_packed(self.buffer.buffers, idx, lens, self.trained_times)
                 self.trained_times += 1
                 continue
             mini_batch = prefetched.pop() if prefetched else self.buffer.gather(idx)
@@ -96,20 +98,6 @@ class Trainer:
         else:
             self._time_steps += inflated
         return played
-
-    def _upload_plans(self, draws):
-        """The (episode, step) unit lists of all the round's learns in ONE host -> device copy, made while the GPU is idle anyway
-        (right behind the round's read).  A plain pageable copy: uploads from a persistent PINNED buffer with non_blocking=True made
-        later HIP calls of the round block for tens of milliseconds on MI355X / ROCm 7 (tools/dbg_round.py: 22.8 -> 33 ms per round)."""
-        import numpy as np
-        pol = self.agents.policy
-        packs = [pol.pack_units(idx, lens, self.buffer.episode_limit) for idx, lens in draws]
-        dev = torch.from_numpy(np.concatenate([u for _, u in packs])).to(self.rolloutWorker.device)
-        plans, off = [], 0
-        for counts, u in packs:
-            plans.append((counts, dev[off:off + u.shape[0]]))
-            off += u.shape[0]
-        return plans
 
     def _finish_dist_round(self, pol):
         if pol.ride_along_sum is None:  # no learn ran this round (train_time == 0): reduce the count by itself

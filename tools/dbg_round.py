@@ -48,12 +48,10 @@ if tr.stream:
         t = time.perf_counter(); a = w.generate_steps(buf, 40); lap('rollout(sync)', t)
         t = time.perf_counter(); buf.sync_host(a); lap('sync_host', t)
         t = time.perf_counter(); draws = [buf.draw(512) for _ in range(4)]; lap('draw', t)
-        if tr._packed:
-            t = time.perf_counter(); plans = tr._upload_plans(draws); lap('upload', t)
         for k in range(4):
             t = time.perf_counter()
             if tr._packed:
-                pol.learn_packed(buf.buffers, draws[k][0], draws[k][1], tr.trained_times, plan=plans[k])
+                pol.learn_packed(buf.buffers, draws[k][0], draws[k][1], tr.trained_times)
             else:
                 tr.agents.train(buf.gather(draws[k][0]), tr.trained_times, max_len=int(draws[k][1][0]))
             host = time.perf_counter() - t
@@ -64,12 +62,11 @@ if tr.stream:
 if tr.stream and tr._packed and os.environ.get('DBG_PROFILE'):
     import cProfile, pstats
     draws = [buf.draw(512) for _ in range(4)]
-    plans = tr._upload_plans(draws)
     torch.cuda.synchronize()
     pr = cProfile.Profile()
     pr.enable()
     for k in range(4):
-        pol.learn_packed(buf.buffers, draws[k][0], draws[k][1], tr.trained_times, plan=plans[k])
+        pol.learn_packed(buf.buffers, draws[k][0], draws[k][1], tr.trained_times)
     pr.disable()
     torch.cuda.synchronize()
     pstats.Stats(pr).sort_stats('tottime').print_stats(18)
@@ -84,11 +81,10 @@ if tr.stream and os.environ.get('DBG_TIMELINE'):
         a = w.generate_steps(buf, 40); mark('rollout queued')
         buf.sync_host(a); mark('synced')
         draws = [buf.draw(512) for _ in range(4)]
-        plans = tr._upload_plans(draws) if tr._packed else None
         mark('plans')
         for k in range(4):
             if tr._packed:
-                pol.learn_packed(buf.buffers, draws[k][0], draws[k][1], tr.trained_times, plan=plans[k])
+                pol.learn_packed(buf.buffers, draws[k][0], draws[k][1], tr.trained_times)
             else:
                 tr.agents.train(buf.gather(draws[k][0]), tr.trained_times, max_len=int(draws[k][1][0]))
             mark('learn %d queued' % k)
@@ -106,11 +102,10 @@ if tr.stream and os.environ.get('DBG_FREE'):
         a = w.generate_steps(buf, 40); mark('roll')
         buf.sync_host(a); mark('sync')
         draws = [buf.draw(512) for _ in range(4)]
-        plans = tr._upload_plans(draws) if tr._packed else None
         mark('plan')
         for k in range(4):
             if tr._packed:
-                pol.learn_packed(buf.buffers, draws[k][0], draws[k][1], tr.trained_times, plan=plans[k])
+                pol.learn_packed(buf.buffers, draws[k][0], draws[k][1], tr.trained_times)
             else:
                 tr.agents.train(buf.gather(draws[k][0]), tr.trained_times, max_len=int(draws[k][1][0]))
             mark('L%d' % k)
