@@ -1,6 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r03/summary; O=gpurun_out/r03/summary/bench_configs.jsonl; : > $O
+mkdir -p gpurun_out/r04/summary; O=gpurun_out/r04/summary/bench_configs.jsonl; : > $O
 # BASELINE configs[2]: MEDA (10x10 is rejected by the reference, meda.py:151-154): smallest legal 4-droplet chip and the CLI default
 python bench.py --env meda --width 30 --length 30 --drop_num 4 --n_envs 4096 --batch_size 256 --train_time 2 --buffer_size 8192 --steps 4 --warmup 1 --no_cpu_baseline 2>/dev/null >> $O
 python bench.py --env meda --width 30 --length 60 --drop_num 4 --n_envs 4096 --batch_size 256 --train_time 2 --buffer_size 8192 --steps 4 --warmup 1 --no_cpu_baseline 2>/dev/null >> $O

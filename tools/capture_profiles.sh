@@ -1,11 +1,11 @@
 #!/bin/bash
 # Capture the measurement records of a round on the MI355X box (run through gpurun from the repo root):
-#   tools/capture_profiles.sh r03          (ONLY_BENCH=1 tools/capture_profiles.sh r03: the bench.py sections only)
+#   tools/capture_profiles.sh r04          (ONLY_BENCH=1 ...: the bench.py sections only; SKIP_PROBES=1: no write-pattern / calibration probes)
 # Writes raw rocprofv3 output under gpurun_out/<round>/ (scratch) and the reduced summaries under
 # gpurun_out/<round>/summary/ -- copy those into profiles/<round>/ and profiles/traffic.json and commit them.
 # Counter passes are separate runs with --kernel-trace only (gpurun refuses --pmc combined with other trace domains).
 set -eo pipefail
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$ROUND
 SUM=$OUT/summary
@@ -26,12 +26,12 @@ cp $(ls $OUT/bench_trace/*/*_kernel_stats.csv | head -1) $SUM/bench_kernel_stats
 
 if [ -n "$ONLY_BENCH" ]; then echo "== ONLY_BENCH: the env-kernel sections are skipped =="; exit 0; fi   # the env kernels did not change
 echo "== env tiers (plain) ==" ; date
-python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 --sizes 4096,65536,262144,655360 --iters 100 --observe > $SUM/env_tiers.jsonl
+python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 --sizes 4096,65536,262144,655360 --msizes 4096,65536,163840 --iters 100 --observe > $SUM/env_tiers.jsonl
 cat $SUM/env_tiers.jsonl
 
 echo "== env kernels under rocprofv3 --kernel-trace ==" ; date
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/env_trace -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 \
-    --sizes 4096,262144 --msizes 65536 --iters 40 --observe > $OUT/env_trace.log 2>&1
+    --sizes 4096,262144 --msizes 65536,163840 --iters 40 --observe > $OUT/env_trace.log 2>&1
 python3 $REPO/tools/reduce_profiles.py trace $OUT/env_trace $SUM/env_kernels_by_grid.csv '(dmfbk|medak)::|k_meda_observe'
 # the roofline batch on its own (same persistent grid as 262 144 chips, so a run of its own): A at 655 360 chips
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/env_trace_big -- python3 $REPO/tools/bench_env.py --cfg A --sizes 655360 --iters 40 --observe \
@@ -42,9 +42,9 @@ echo "== HBM traffic counters ==" ; date
 # sizes 4096 + 262144 (MEDA: 65536) only: the fused 4096-chip launch and the 65536-chip step-only launch share a grid size,
 # and so do the persistent MEDA observation launches of all batch sizes
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 \
-    --sizes 4096,262144 --msizes 65536 --iters 24 --observe --labels $OUT/labels.json > $OUT/pmc_fetch.log 2>&1
+    --sizes 4096,262144 --msizes 65536,163840 --iters 24 --observe --labels $OUT/labels.json > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/tools/bench_env.py --cfg A,D,E,M30,M60,M30v2 \
-    --sizes 4096,262144 --msizes 65536 --iters 24 --observe > $OUT/pmc_write.log 2>&1
+    --sizes 4096,262144 --msizes 65536,163840 --iters 24 --observe > $OUT/pmc_write.log 2>&1
 python3 $REPO/tools/reduce_profiles.py traffic $OUT/pmc_fetch $OUT/pmc_write $SUM/traffic.json $OUT/labels.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_big -- python3 $REPO/tools/bench_env.py --cfg A --sizes 655360 --iters 24 --observe \
     --labels $OUT/labels_big.json > $OUT/pmc_fetch_big.log 2>&1
@@ -57,6 +57,7 @@ a = json.load(open('$SUM/traffic.json')); b = json.load(open('$OUT/traffic_big.j
 a['detail'] += b.pop('detail'); b.pop('note', None); a.update(b)
 json.dump(a, open('$SUM/traffic.json', 'w'), indent=1)
 PY
+if [ -n "$SKIP_PROBES" ]; then echo "== SKIP_PROBES: the write-pattern and calibration probes are not re-run =="; exit 0; fi
 echo "== write-pattern and counter-calibration probes ==" ; date
 make -C $REPO/tools/probe -s bin/write_probe bin/fetch_calib || true   # built from source, never a checked-in binary
 if [ -x $REPO/tools/probe/bin/write_probe ]; then
