@@ -90,7 +90,8 @@ int rollout_post_step(int32_t n_envs, int32_t episode_limit, int32_t t, uint8_t 
  * round is a fixed number of lock-steps in which EVERY row is live, however short the policy's episodes are.
  *
  * rollout_stage: per-chip state of the episode being played (DEVICE pointers, caller-owned; zero-initialised):
- *   d_t_ep int32[E]           step index inside the running episode
+ *   d_t_ep int32[2][E]        step index inside the running episode, double-buffered: the call with parity p reads row p and
+ *                             writes row 1 - p (rollout_gru_head_select_stream of the same lock-step is given row p)
  *   d_o0 int8[E][row]         its first observation;   d_o_next int8[E][T][row]  observation after each step (row = n * obs bytes)
  *   d_u int8[E][T][n]         d_onehot int8[E][T][n][A]      d_r float32[E][T]
  *   d_ep_acc float64[E][3]    running (reward, constraints, success) of the episode (rollout.py:122-124)
@@ -139,12 +140,14 @@ int rollout_gru_head_select_stream(const float *d_igates, const float *d_hgates,
  *   (rollout.py:131-141: rows behind the end are zeros, padded = 1, terminated = 1, avail_u = avail_u_next = 0; o[t] = o0 for
  *   t == 0, o_next[t - 1] after), ring d_len / d_stats of the slot and the chip's counters are written, the running sums, the
  *   chip's rows of d_hidden (float32[E*n][hidden]; policy.init_hidden, rollout.py:112) and d_last_onehot (rollout.py:110) are
- *   cleared, d_close_slot[e] = that slot and d_t_ep[e] = 0; every other chip gets d_close_slot[e] = -1 and d_t_ep[e] += 1.
+ *   cleared, d_close_slot[e] = that slot and the chip's step index becomes 0; every other chip gets d_close_slot[e] = -1 and its
+ *   step index + 1.
  *   Then ring cursor / size / total advance, *d_epsilon = max(*d_epsilon - anneal * n_envs, min_epsilon) (every chip played a
  *   step; epsilon_anneal_scale == 'step', rollout.py:126-127), *d_draw += 1.
  * The ring state is double-buffered inside one call (the cursor is read by every closing chip while the new one is published):
- * parity 0 reads ring->d_state and writes stage->d_state_alt, parity 1 the other way round; the caller alternates and, after an odd
- * number of calls, copies d_state_alt back.  The caller then resets the closed chips' env (dmfb_vec_reset / meda_vec_reset with
+ * parity 0 reads ring->d_state and writes stage->d_state_alt, parity 1 the other way round (stage->d_t_ep likewise, rows 0 / 1: the
+ * observation rows of an ended episode are copied by ALL the workgroups of the launch, which read its step index while the chip's
+ * own workgroup resets it); the caller alternates and, after an odd number of calls, copies the second buffers back.  n_envs <= 32 768.  The caller then resets the closed chips' env (dmfb_vec_reset / meda_vec_reset with
  * d_term as mask), which also rewrites their rows of d_obs_new with the first observation of the next episode.
  * d_obs_term (may be NULL): when the env resets ended chips INSIDE its transition launch (DMFB_STEP_AUTORESET with
  * dmfb_vec_step_out::d_obs_terminal) d_obs_new already holds an ended chip's next first observation and its terminal observation

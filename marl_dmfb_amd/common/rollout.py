@@ -314,7 +314,7 @@ class RolloutWorker(Evaluator):
         st.hidden = z((E * n, self.agents.args.rnn_hidden_dim), torch.float32)
         st.last_action = z((E, n, A), torch.int8)
         st.actions = z((E, n), torch.int32)
-        st.t_ep = z((E,), torch.int32)
+        st.t_ep = z((2, E), torch.int32)   # double-buffered (include/rollout_ops.h: rollout_stream_step)
         st.o0, st.o_next = z((E, n * O), torch.int8), z((E, T, n * O), torch.int8)
         st.u, st.onehot, st.r = z((E, T, n), torch.int8), z((E, T, n, A), torch.int8), z((E, T), torch.float32)
         st.ep_acc, st.chip_acc = z((E, 3), torch.float64), z((E, 4), torch.int64)
@@ -366,7 +366,7 @@ class RolloutWorker(Evaluator):
                                                     vp(net.fc1.bias.data_ptr()), E, n, st.hidden.shape[1], A, vp(st.eps.data_ptr()), 0,
                                                     self.rng_seed, vp(self._draw.data_ptr()), vp(st.actions.data_ptr()),
                                                     vp(st.last_action.data_ptr()), vp(st.u.data_ptr()), vp(st.onehot.data_ptr()), T,
-                                                    vp(st.t_ep.data_ptr()), None, stream)
+                                                    vp(st.t_ep[s & 1].data_ptr()), None, stream)
             if rc != 0:
                 raise RuntimeError('rollout_gru_head_select_stream failed: %d (hip %d)' % (rc, lib.rollout_last_hip_error()))
             u = self.uniforms_fn(s) if self.uniforms_fn is not None else None
@@ -387,6 +387,7 @@ class RolloutWorker(Evaluator):
         if K & 1:   # the double-buffered observation and ring state end in their second buffers
             st.obs[0].copy_(st.obs[1])
             st.buffer.ring_state.copy_(st.state_alt)
+            st.t_ep[0].copy_(st.t_ep[1])
 
     stream_step_hook = None
 

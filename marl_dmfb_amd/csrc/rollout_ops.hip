@@ -243,32 +243,39 @@ struct RingPtrs {
 // bytes != 0 among the four of a word
 __device__ __forceinline__ int nz_bytes(uint32_t w) { return __popc((w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u); }
 
-// One workgroup per chip.  (1) the chip's row of this lock-step is appended to its staged episode and its running sums advance;
-// (2) if its episode ended, its ring slot is (cursor + number of LOWER-numbered chips that also ended in this lock-step) -- every
-// closing workgroup counts the flags below its own chip, so the slots are handed out in chip order whatever the scheduling (graph
-// replay == eager play, bit for bit) and no single workgroup walks all the chips; the staged episode is written into the slot
-// with the padding rules of rollout.py:131-141 (zeros, padded = terminated = 1, avail 0 behind the end), and the chip's recurrent
-// state is cleared for the next episode (policy.init_hidden, rollout.py:112).  The workgroup of the LAST chip counts all flags
-// and publishes the new cursor / fill level / episode count, epsilon and the draw counter; the ring state is double-buffered
-// (state_in is only read, state_out only written) because the other workgroups read the cursor while it does.
-constexpr int kStreamBlock = 256;  // (1024 threads move a closing episode faster -- 50 vs 82 us for 60 MEDA steps -- but make every launch without a close 10 us slower)
+// One workgroup per chip.  (1) the chip's row of this lock-step is appended to its staged episode and its running sums advance.
+// (2) EVERY workgroup scans the termination flags of all chips (16 bytes per thread and pass, a block-wide prefix sum over the
+// 16-chip groups): the k-th ended chip in ASCENDING chip order closes into ring slot (cursor + k) mod S -- deterministic whatever
+// the scheduling (graph replay == eager play, bit for bit), and no single workgroup walks the chips alone.  (3) A chip whose
+// episode ended writes the small tensors of its ring slot, its statistics, and clears its recurrent state (policy.init_hidden,
+// rollout.py:112).  (4) The bulk of the close -- the 2 x T observation rows of every ended episode, with the padding of
+// rollout.py:131-141 -- is cut into chunks of kChunk words and shared by ALL the workgroups of the launch (workgroup e takes chunks
+// e, e + E, ...): one workgroup copying its own episode alone took 12 us (DMFB, 40 x 980 B) to 82 us (MEDA, 60 x 4340 B) even with
+// sixteen loads in flight per thread, and any lock-step with a single close paid that.  The helpers read only what this launch does
+// not write: staged rows of EARLIER steps, this step's row from the env's output, the step index through the double-buffered t_ep.
+// The workgroup of the LAST chip publishes the new cursor / fill level / episode count (double-buffered ring state: the cursor is
+// read by everybody while it is advanced), epsilon and the draw counter.
+constexpr int kStreamBlock = 256;
+constexpr int kStreamU = 8;                          // independent loads in flight per thread before the first store
+constexpr int kChunk = kStreamBlock * kStreamU;      // words of the (o, o_next) index space per work item
+constexpr int kMaxGroups = 2048;                     // 16-chip groups: E <= 32 768 (the fused-launch range of the env kernels)
 template <typename V>
 __global__ __launch_bounds__(kStreamBlock) void k_stream_step(int E, int n, int A, int T, int S, int row_v, int H, const V *__restrict__ obs_prev,
                                                      const V *__restrict__ obs_new, const V *__restrict__ obs_term, const uint8_t *__restrict__ term,
                                                      const double *__restrict__ team_reward, const void *__restrict__ constraints, int cons_f64,
-                                                     const uint8_t *__restrict__ success, int32_t *__restrict__ t_ep, V *__restrict__ stage_o0,
-                                                     V *__restrict__ stage_o_next, const int8_t *__restrict__ stage_u,
+                                                     const uint8_t *__restrict__ success, const int32_t *__restrict__ t_in, int32_t *__restrict__ t_out,
+                                                     V *__restrict__ stage_o0, V *__restrict__ stage_o_next, const int8_t *__restrict__ stage_u,
                                                      const int8_t *__restrict__ stage_onehot, float *__restrict__ stage_r,
                                                      double *__restrict__ ep_acc, int64_t *__restrict__ chip_acc, int32_t *__restrict__ close_slot,
                                                      RingPtrs ring, const int64_t *__restrict__ state_in, int64_t *__restrict__ state_out,
                                                      float *__restrict__ hidden, int8_t *__restrict__ last_onehot, float *__restrict__ eps_p,
                                                      float anneal, float min_eps, uint32_t *__restrict__ draw_p) {
-    __shared__ int s_cnt[kStreamBlock / 64];
-    const int e = blockIdx.x, tid = threadIdx.x;
-    const int t = t_ep[e];
+    __shared__ int s_pref[kMaxGroups + 1];   // ended chips in the groups below group g; [groups] = all of them
+    __shared__ int s_wave[kStreamBlock / 64];
+    __shared__ int s_base;
+    const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = t_in[e];
     const bool tm = term[e] != 0;
-    // the observation after this step: with the env's reset inside the transition launch obs_new already shows an ended chip's
-    // NEXT episode and the terminal observation comes in obs_term (dmfb_vec.h: d_obs_terminal)
     const V *on = (tm && obs_term ? obs_term : obs_new) + (size_t)e * row_v, *op = obs_prev + (size_t)e * row_v;
     V *so = stage_o_next + (size_t)e * T * row_v;
     for (int k = tid; k < row_v; k += kStreamBlock) {
@@ -286,98 +293,130 @@ __global__ __launch_bounds__(kStreamBlock) void k_stream_step(int E, int n, int 
         ep_acc[(size_t)e * 3 + 1] = tm ? 0.0 : cons;
         ep_acc[(size_t)e * 3 + 2] = tm ? 0.0 : succ;
         chip_acc[(size_t)e * 4 + 3] += 1;   // env steps played
+        t_out[e] = tm ? 0 : t + 1;
+        if (!tm) close_slot[e] = -1;
     }
-    const bool last = e == E - 1;
-    if (!tm && !last) {   // (uniform) the episode goes on
-        if (tid == 0) { t_ep[e] = t + 1; close_slot[e] = -1; }
-        return;
-    }
-    // rank = chips below e whose episode ended too (16 flag bytes per thread and pass)
-    int c = 0;
-    for (int i = tid * 16; i < e; i += kStreamBlock * 16) {
-        if (i + 16 <= e && ((size_t)(term + i) & 15) == 0) {
-            const uint4 w = *(const uint4 *)(term + i);
-            c += nz_bytes(w.x) + nz_bytes(w.y) + nz_bytes(w.z) + nz_bytes(w.w);
-        } else {
-            for (int k = i; k < min(i + 16, e); ++k) c += term[k] != 0;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-    if ((tid & 63) == 0) s_cnt[tid >> 6] = c;
+    // ---- ended chips per 16-chip group, exclusive prefix over the groups
+    const int groups = (E + 15) / 16;
+    if (tid == 0) s_base = 0;
     __syncthreads();
-    int rank = 0;
-    for (int w = 0; w < kStreamBlock / 64; ++w) rank += s_cnt[w];
+    for (int g0 = 0; g0 < groups; g0 += kStreamBlock) {
+        const int g = g0 + tid;
+        int c = 0;
+        if (g < groups) {
+            const int i = g * 16;
+            if (i + 16 <= E && ((size_t)(term + i) & 15) == 0) {
+                const uint4 w = *(const uint4 *)(term + i);
+                c = nz_bytes(w.x) + nz_bytes(w.y) + nz_bytes(w.z) + nz_bytes(w.w);
+            } else {
+                for (int k = i; k < min(i + 16, E); ++k) c += term[k] != 0;
+            }
+        }
+        int inc = c;   // inclusive prefix inside the wave
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (g < groups) s_pref[g] = off + inc - c;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < kStreamBlock / 64; ++w) tot += s_wave[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    const int n_close = s_base;
+    if (tid == 0) s_pref[groups] = n_close;
     const long cursor0 = state_in[0];
-    if (last && tid == 0) {
-        const long closed = rank + (tm ? 1 : 0);
-        state_out[0] = (cursor0 + closed) % S;
-        state_out[1] = min((long)S, state_in[1] + closed);
-        state_out[2] = state_in[2] + closed;
+    if (e == E - 1 && tid == 0) {
+        state_out[0] = (cursor0 + n_close) % S;
+        state_out[1] = min((long)S, state_in[1] + n_close);
+        state_out[2] = state_in[2] + n_close;
         state_out[3] = state_in[3];
         if (anneal > 0.0f) *eps_p = fmaxf(*eps_p - anneal * (float)E, min_eps);   // every chip played a step (rollout.py:126-127)
         if (draw_p) *draw_p += 1u;
     }
-    if (!tm) {
-        if (tid == 0) { t_ep[e] = t + 1; close_slot[e] = -1; }
-        return;
+    if (n_close == 0) return;   // (uniform)
+    __syncthreads();            // s_pref[groups]
+    // ---- the chip's own close: everything but the observation rows
+    if (tm) {
+        int rank = s_pref[e >> 4];
+        for (int k = e & ~15; k < e; ++k) rank += term[k] != 0;
+        const int slot = (int)((cursor0 + rank) % S);
+        const int len = t + 1;
+        if (tid == 0) {
+            const long infl = succ > 0.0 ? len : T;   // `steps` is forced to episode_limit when not successful (rollout.py:148-149)
+            ring.len[slot] = len;
+            ring.stats[(size_t)slot * 4] = rew;
+            ring.stats[(size_t)slot * 4 + 1] = (double)infl;
+            ring.stats[(size_t)slot * 4 + 2] = cons;
+            ring.stats[(size_t)slot * 4 + 3] = succ;
+            chip_acc[(size_t)e * 4] += 1;
+            chip_acc[(size_t)e * 4 + 1] += infl;
+            chip_acc[(size_t)e * 4 + 2] += succ > 0.0 ? 1 : 0;
+            close_slot[e] = slot;
+        }
+        for (int i = tid; i < T * n * A; i += kStreamBlock) {
+            const int tt = i / (n * A);
+            const int8_t live = (int8_t)(tt < len);
+            ring.u_onehot[(size_t)slot * T * n * A + i] = live ? stage_onehot[(size_t)e * T * n * A + i] : (int8_t)0;
+            ring.avail_u[(size_t)slot * T * n * A + i] = live;
+            ring.avail_u_next[(size_t)slot * T * n * A + i] = live;
+        }
+        for (int i = tid; i < T * n; i += kStreamBlock) ring.u[(size_t)slot * T * n + i] = i / n < len ? stage_u[(size_t)e * T * n + i] : (int8_t)0;
+        for (int tt = tid; tt < T; tt += kStreamBlock) {
+            ring.r[(size_t)slot * T + tt] = tt < len ? (tt == t ? (float)team_reward[e] : stage_r[(size_t)e * T + tt]) : 0.0f;
+            ring.padded[(size_t)slot * T + tt] = (uint8_t)(tt >= len);
+            ring.terminated[(size_t)slot * T + tt] = (uint8_t)(tt >= len - 1);
+        }
+        for (int i = tid; i < n * H; i += kStreamBlock) hidden[(size_t)e * n * H + i] = 0.0f;
+        for (int i = tid; i < n * A; i += kStreamBlock) last_onehot[(size_t)e * n * A + i] = 0;
     }
-    const int slot = (int)((cursor0 + rank) % S);
-    const int len = t + 1;
-    if (tid == 0) {
-        const long infl = succ > 0.0 ? len : T;   // `steps` is forced to episode_limit when not successful (rollout.py:148-149)
-        ring.len[slot] = len;
-        ring.stats[(size_t)slot * 4] = rew;
-        ring.stats[(size_t)slot * 4 + 1] = (double)infl;
-        ring.stats[(size_t)slot * 4 + 2] = cons;
-        ring.stats[(size_t)slot * 4 + 3] = succ;
-        chip_acc[(size_t)e * 4] += 1;
-        chip_acc[(size_t)e * 4 + 1] += infl;
-        chip_acc[(size_t)e * 4 + 2] += succ > 0.0 ? 1 : 0;
-        close_slot[e] = slot;
-        t_ep[e] = 0;
-    }
-    // o[tt] = first observation (tt == 0) or o_next[tt - 1]; o_next[tt] as staged; this step's row comes from obs_new (the
-    // staged copy above was written by other threads of this workgroup).  ONE workgroup moves the whole episode (2 x T rows), so
-    // the loop is built for memory-level parallelism: 2 x kU independent loads per thread are in flight before the first store
-    // (one load -> store per iteration ran at one HBM latency per element: 160 us for a 60-step MEDA episode).
-    V *ro = (V *)ring.o + (size_t)slot * T * row_v, *rn = (V *)ring.o_next + (size_t)slot * T * row_v;
-    const V *o0 = t == 0 ? op : stage_o0 + (size_t)e * row_v;
-    constexpr int kU = 8;
+    // ---- the observation rows of every ended episode, shared by all workgroups.  o[tt] = first observation (tt == 0) or
+    // o_next[tt - 1]; o_next[tt] as staged; the row of THIS step comes from the env's output (its staged copy is being written by
+    // the chip's own workgroup in this very launch)
     const int total = T * row_v;
-    for (int base = tid; base < total; base += kStreamBlock * kU) {
-        V vo[kU], vn[kU];
+    const int chunks = (total + kChunk - 1) / kChunk;
+    for (long j = e; j < (long)n_close * chunks; j += E) {
+        const int ci = (int)(j / chunks), ch = (int)(j - (long)ci * chunks);
+        int lo = 0, hi = groups;   // last group whose prefix is <= ci (broadcast LDS reads)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pref[mid] <= ci) lo = mid; else hi = mid;
+        }
+        int c = lo * 16, left = ci - s_pref[lo];
+        for (;; ++c) {   // the (left + 1)-th ended chip of the group
+            if (term[c] != 0 && left-- == 0) break;
+        }
+        const int tc = t_in[c], len = tc + 1;
+        const int slot = (int)((cursor0 + ci) % S);
+        const V *onc = (obs_term ? obs_term : obs_new) + (size_t)c * row_v;
+        const V *soc = stage_o_next + (size_t)c * T * row_v;
+        const V *o0 = tc == 0 ? obs_prev + (size_t)c * row_v : stage_o0 + (size_t)c * row_v;
+        V *ro = (V *)ring.o + (size_t)slot * T * row_v, *rn = (V *)ring.o_next + (size_t)slot * T * row_v;
+        V vo[kStreamU], vn[kStreamU];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int i = base + u * kStreamBlock;
+        for (int u = 0; u < kStreamU; ++u) {
+            const int i = ch * kChunk + u * kStreamBlock + tid;
             const int tt = i / row_v, k = i - tt * row_v;
             vo[u] = 0;
             vn[u] = 0;
             if (i < total && tt < len) {
-                vn[u] = tt == t ? on[k] : so[(size_t)tt * row_v + k];
-                vo[u] = tt == 0 ? o0[k] : so[(size_t)(tt - 1) * row_v + k];
+                vn[u] = tt == tc ? onc[k] : soc[(size_t)tt * row_v + k];
+                vo[u] = tt == 0 ? o0[k] : soc[(size_t)(tt - 1) * row_v + k];
             }
         }
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int i = base + u * kStreamBlock;
+        for (int u = 0; u < kStreamU; ++u) {
+            const int i = ch * kChunk + u * kStreamBlock + tid;
             if (i < total) { ro[i] = vo[u]; rn[i] = vn[u]; }
         }
     }
-    for (int i = tid; i < T * n * A; i += kStreamBlock) {
-        const int tt = i / (n * A);
-        const int8_t live = (int8_t)(tt < len);
-        ring.u_onehot[(size_t)slot * T * n * A + i] = live ? stage_onehot[(size_t)e * T * n * A + i] : (int8_t)0;
-        ring.avail_u[(size_t)slot * T * n * A + i] = live;
-        ring.avail_u_next[(size_t)slot * T * n * A + i] = live;
-    }
-    for (int i = tid; i < T * n; i += kStreamBlock) ring.u[(size_t)slot * T * n + i] = i / n < len ? stage_u[(size_t)e * T * n + i] : (int8_t)0;
-    for (int tt = tid; tt < T; tt += kStreamBlock) {
-        ring.r[(size_t)slot * T + tt] = tt < len ? (tt == t ? (float)team_reward[e] : stage_r[(size_t)e * T + tt]) : 0.0f;
-        ring.padded[(size_t)slot * T + tt] = (uint8_t)(tt >= len);
-        ring.terminated[(size_t)slot * T + tt] = (uint8_t)(tt >= len - 1);
-    }
-    for (int i = tid; i < n * H; i += kStreamBlock) hidden[(size_t)e * n * H + i] = 0.0f;
-    for (int i = tid; i < n * A; i += kStreamBlock) last_onehot[(size_t)e * n * A + i] = 0;
 }
 
 thread_local int g_last = 0;
@@ -509,7 +548,7 @@ int rollout_stream_step(int32_t n_envs, int32_t n_agents, int32_t n_actions, int
                         float *d_epsilon, float anneal, float min_epsilon, uint32_t *d_draw, void *stream) {
     if (!ring || !stage || !d_obs_prev || !d_obs_new || !d_term || !d_team_reward || !d_constraints || !d_success || !d_hidden ||
         !d_last_onehot || n_envs < 0 || n_agents < 1 || n_actions < 1 || episode_limit < 1 || obs_row_bytes < 1 || hidden < 1 ||
-        ring->slots < 1 || !stage->d_t_ep || !stage->d_close_slot || !stage->d_o0 || !stage->d_o_next || !stage->d_u || !stage->d_onehot ||
+        ring->slots < 1 || n_envs > 16 * kMaxGroups || !stage->d_t_ep || !stage->d_close_slot || !stage->d_o0 || !stage->d_o_next || !stage->d_u || !stage->d_onehot ||
         !stage->d_r || !stage->d_ep_acc || !stage->d_chip_acc || !stage->d_state_alt || !ring->d_o || !ring->d_o_next || !ring->d_u ||
         !ring->d_u_onehot || !ring->d_avail_u || !ring->d_avail_u_next || !ring->d_r || !ring->d_padded || !ring->d_terminated ||
         !ring->d_len || !ring->d_stats || !ring->d_state || (anneal > 0.0f && !d_epsilon))
@@ -519,19 +558,21 @@ int rollout_stream_step(int32_t n_envs, int32_t n_agents, int32_t n_actions, int
                       ring->d_padded, ring->d_terminated, ring->d_len, ring->d_stats};
     const int64_t *st_in = parity ? stage->d_state_alt : ring->d_state;
     int64_t *st_out = parity ? ring->d_state : stage->d_state_alt;
+    const int32_t *t_in = stage->d_t_ep + (parity ? n_envs : 0);   // d_t_ep is int32[2][E]: the step index is double-buffered too
+    int32_t *t_out = stage->d_t_ep + (parity ? 0 : n_envs);
     const bool dw = obs_row_bytes % 4 == 0 &&
                     ((size_t)d_obs_prev | (size_t)d_obs_new | (size_t)d_obs_term | (size_t)stage->d_o0 | (size_t)stage->d_o_next | (size_t)ring->d_o | (size_t)ring->d_o_next) % 4 == 0;
     (void)hipGetLastError();
     if (dw)
         hipLaunchKernelGGL((k_stream_step<uint32_t>), dim3((unsigned)n_envs), dim3(kStreamBlock), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
                            episode_limit, ring->slots, obs_row_bytes / 4, hidden, (const uint32_t *)d_obs_prev, (const uint32_t *)d_obs_new,
-                           (const uint32_t *)d_obs_term, d_term, d_team_reward, d_constraints, constraints_f64, d_success, stage->d_t_ep, (uint32_t *)stage->d_o0,
+                           (const uint32_t *)d_obs_term, d_term, d_team_reward, d_constraints, constraints_f64, d_success, t_in, t_out, (uint32_t *)stage->d_o0,
                            (uint32_t *)stage->d_o_next, stage->d_u, stage->d_onehot, stage->d_r, stage->d_ep_acc, stage->d_chip_acc,
                            stage->d_close_slot, rp, st_in, st_out, d_hidden, d_last_onehot, d_epsilon, anneal, min_epsilon, d_draw);
     else
         hipLaunchKernelGGL((k_stream_step<int8_t>), dim3((unsigned)n_envs), dim3(kStreamBlock), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
                            episode_limit, ring->slots, obs_row_bytes, hidden, d_obs_prev, d_obs_new, d_obs_term, d_term, d_team_reward, d_constraints,
-                           constraints_f64, d_success, stage->d_t_ep, stage->d_o0, stage->d_o_next, stage->d_u, stage->d_onehot, stage->d_r,
+                           constraints_f64, d_success, t_in, t_out, stage->d_o0, stage->d_o_next, stage->d_u, stage->d_onehot, stage->d_r,
                            stage->d_ep_acc, stage->d_chip_acc, stage->d_close_slot, rp, st_in, st_out, d_hidden, d_last_onehot, d_epsilon,
                            anneal, min_epsilon, d_draw);
     return finish();
