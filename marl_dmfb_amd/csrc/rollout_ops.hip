@@ -258,8 +258,9 @@ __device__ __forceinline__ int nz_bytes(uint32_t w) { return __popc((w | ((w & 0
 constexpr int kStreamBlock = 256;
 constexpr int kStreamU = 8;                          // independent loads in flight per thread before the first store
 constexpr int kChunk = kStreamBlock * kStreamU;      // words of the (o, o_next) index space per work item
-constexpr int kMaxGroups = 2048;                     // 16-chip groups: E <= 32 768 (the fused-launch range of the env kernels)
-template <typename V>
+constexpr int kMaxGroups = 2048;
+constexpr int kCoopMinWords = 16384;                 // episodes of more words than this are copied by all workgroups together                     // 16-chip groups: E <= 32 768 (the fused-launch range of the env kernels)
+template <typename V, bool COOP>
 __global__ __launch_bounds__(kStreamBlock) void k_stream_step(int E, int n, int A, int T, int S, int row_v, int H, const V *__restrict__ obs_prev,
                                                      const V *__restrict__ obs_new, const V *__restrict__ obs_term, const uint8_t *__restrict__ term,
                                                      const double *__restrict__ team_reward, const void *__restrict__ constraints, int cons_f64,
@@ -296,58 +297,9 @@ __global__ __launch_bounds__(kStreamBlock) void k_stream_step(int E, int n, int 
         t_out[e] = tm ? 0 : t + 1;
         if (!tm) close_slot[e] = -1;
     }
-    // ---- ended chips per 16-chip group, exclusive prefix over the groups
-    const int groups = (E + 15) / 16;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int g0 = 0; g0 < groups; g0 += kStreamBlock) {
-        const int g = g0 + tid;
-        int c = 0;
-        if (g < groups) {
-            const int i = g * 16;
-            if (i + 16 <= E && ((size_t)(term + i) & 15) == 0) {
-                const uint4 w = *(const uint4 *)(term + i);
-                c = nz_bytes(w.x) + nz_bytes(w.y) + nz_bytes(w.z) + nz_bytes(w.w);
-            } else {
-                for (int k = i; k < min(i + 16, E); ++k) c += term[k] != 0;
-            }
-        }
-        int inc = c;   // inclusive prefix inside the wave
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(inc, o);
-            if (lane >= o) inc += v;
-        }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        int off = s_base;
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
-        if (g < groups) s_pref[g] = off + inc - c;
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int w = 0; w < kStreamBlock / 64; ++w) tot += s_wave[w];
-            s_base += tot;
-        }
-        __syncthreads();
-    }
-    const int n_close = s_base;
-    if (tid == 0) s_pref[groups] = n_close;
-    const long cursor0 = state_in[0];
-    if (e == E - 1 && tid == 0) {
-        state_out[0] = (cursor0 + n_close) % S;
-        state_out[1] = min((long)S, state_in[1] + n_close);
-        state_out[2] = state_in[2] + n_close;
-        state_out[3] = state_in[3];
-        if (anneal > 0.0f) *eps_p = fmaxf(*eps_p - anneal * (float)E, min_eps);   // every chip played a step (rollout.py:126-127)
-        if (draw_p) *draw_p += 1u;
-    }
-    if (n_close == 0) return;   // (uniform)
-    __syncthreads();            // s_pref[groups]
-    // ---- the chip's own close: everything but the observation rows
-    if (tm) {
-        int rank = s_pref[e >> 4];
-        for (int k = e & ~15; k < e; ++k) rank += term[k] != 0;
-        const int slot = (int)((cursor0 + rank) % S);
+    // everything of a chip's close but the observation rows (called by the chip's own workgroup)
+    auto close_small = [&](int slot, int rank) {
+        (void)rank;
         const int len = t + 1;
         if (tid == 0) {
             const long infl = succ > 0.0 ? len : T;   // `steps` is forced to episode_limit when not successful (rollout.py:148-149)
@@ -376,6 +328,126 @@ __global__ __launch_bounds__(kStreamBlock) void k_stream_step(int E, int n, int 
         }
         for (int i = tid; i < n * H; i += kStreamBlock) hidden[(size_t)e * n * H + i] = 0.0f;
         for (int i = tid; i < n * A; i += kStreamBlock) last_onehot[(size_t)e * n * A + i] = 0;
+    };
+    if constexpr (!COOP) {
+        // Small episodes (T x row words <= kCoopMinWords: config A): the chip's own workgroup copies its episode -- ~12 us on a
+        // lock-step with a close -- and a lock-step WITHOUT a close costs nothing beyond the staging: only workgroups of ended chips
+        // (and the last one, which publishes the totals) look at the other chips' flags.  The shared form below costs every
+        // launch ~2.5 us (flag scan + barrier in all 4096 workgroups) and pays off when one episode is tens of thousands of words.
+        const bool last = e == E - 1;
+        if (!tm && !last) return;   // (uniform)
+        int c = 0;
+        for (int i = tid * 16; i < e; i += kStreamBlock * 16) {
+            if (i + 16 <= e && ((size_t)(term + i) & 15) == 0) {
+                const uint4 w = *(const uint4 *)(term + i);
+                c += nz_bytes(w.x) + nz_bytes(w.y) + nz_bytes(w.z) + nz_bytes(w.w);
+            } else {
+                for (int k = i; k < min(i + 16, e); ++k) c += term[k] != 0;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+        if (lane == 0) s_wave[wave] = c;
+        __syncthreads();
+        int rank = 0;
+        for (int w = 0; w < kStreamBlock / 64; ++w) rank += s_wave[w];
+        const long cursor0 = state_in[0];
+        if (last && tid == 0) {
+            const long closed = rank + (tm ? 1 : 0);
+            state_out[0] = (cursor0 + closed) % S;
+            state_out[1] = min((long)S, state_in[1] + closed);
+            state_out[2] = state_in[2] + closed;
+            state_out[3] = state_in[3];
+            if (anneal > 0.0f) *eps_p = fmaxf(*eps_p - anneal * (float)E, min_eps);
+            if (draw_p) *draw_p += 1u;
+        }
+        if (!tm) return;
+        const int slot = (int)((cursor0 + rank) % S);
+        close_small(slot, rank);
+        const int len = t + 1, total = T * row_v;
+        V *ro = (V *)ring.o + (size_t)slot * T * row_v, *rn = (V *)ring.o_next + (size_t)slot * T * row_v;
+        const V *o0 = t == 0 ? op : stage_o0 + (size_t)e * row_v;
+        for (int base = tid; base < total; base += kChunk) {
+            V vo[kStreamU], vn[kStreamU];
+#pragma unroll
+            for (int u = 0; u < kStreamU; ++u) {
+                const int i = base + u * kStreamBlock;
+                const int tt = i / row_v, k = i - tt * row_v;
+                vo[u] = 0;
+                vn[u] = 0;
+                if (i < total && tt < len) {
+                    vn[u] = tt == t ? on[k] : so[(size_t)tt * row_v + k];
+                    vo[u] = tt == 0 ? o0[k] : so[(size_t)(tt - 1) * row_v + k];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kStreamU; ++u) {
+                const int i = base + u * kStreamBlock;
+                if (i < total) { ro[i] = vo[u]; rn[i] = vn[u]; }
+            }
+        }
+        return;
+    }
+    // ---- ended chips per 16-chip group, exclusive prefix over the groups.  A cheap first look (one 16-byte load per thread and
+    // pass, ONE barrier) keeps the lock-steps in which no episode ended -- most of them under a policy that does not finish -- off
+    // the scan
+    const int groups = (E + 15) / 16;
+    auto group_count = [&](int g) {
+        int c = 0;
+        if (g < groups) {
+            const int i = g * 16;
+            if (i + 16 <= E && ((size_t)(term + i) & 15) == 0) {
+                const uint4 w = *(const uint4 *)(term + i);
+                c = nz_bytes(w.x) + nz_bytes(w.y) + nz_bytes(w.z) + nz_bytes(w.w);
+            } else {
+                for (int k = i; k < min(i + 16, E); ++k) c += term[k] != 0;
+            }
+        }
+        return c;
+    };
+    int seen = 0;
+    for (int g0 = 0; g0 < groups; g0 += kStreamBlock) seen |= group_count(g0 + tid);
+    if (tid == 0) s_base = 0;
+    if (__syncthreads_or(seen)) {
+        for (int g0 = 0; g0 < groups; g0 += kStreamBlock) {
+            const int g = g0 + tid;
+            const int c = group_count(g);
+            int inc = c;   // inclusive prefix inside the wave
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(inc, o);
+                if (lane >= o) inc += v;
+            }
+            if (lane == 63) s_wave[wave] = inc;
+            __syncthreads();
+            int off = s_base;
+            for (int w = 0; w < wave; ++w) off += s_wave[w];
+            if (g < groups) s_pref[g] = off + inc - c;
+            __syncthreads();
+            if (tid == 0) {
+                int tot = 0;
+                for (int w = 0; w < kStreamBlock / 64; ++w) tot += s_wave[w];
+                s_base += tot;
+            }
+            __syncthreads();
+        }
+    }
+    const int n_close = s_base;
+    if (tid == 0) s_pref[groups] = n_close;
+    const long cursor0 = state_in[0];
+    if (e == E - 1 && tid == 0) {
+        state_out[0] = (cursor0 + n_close) % S;
+        state_out[1] = min((long)S, state_in[1] + n_close);
+        state_out[2] = state_in[2] + n_close;
+        state_out[3] = state_in[3];
+        if (anneal > 0.0f) *eps_p = fmaxf(*eps_p - anneal * (float)E, min_eps);   // every chip played a step (rollout.py:126-127)
+        if (draw_p) *draw_p += 1u;
+    }
+    if (n_close == 0) return;   // (uniform)
+    __syncthreads();            // s_pref[groups]
+    // ---- the chip's own close: everything but the observation rows
+    if (tm) {
+        int rank = s_pref[e >> 4];
+        for (int k = e & ~15; k < e; ++k) rank += term[k] != 0;
+        close_small((int)((cursor0 + rank) % S), rank);
     }
     // ---- the observation rows of every ended episode, shared by all workgroups.  o[tt] = first observation (tt == 0) or
     // o_next[tt - 1]; o_next[tt] as staged; the row of THIS step comes from the env's output (its staged copy is being written by
@@ -563,14 +635,21 @@ int rollout_stream_step(int32_t n_envs, int32_t n_agents, int32_t n_actions, int
     const bool dw = obs_row_bytes % 4 == 0 &&
                     ((size_t)d_obs_prev | (size_t)d_obs_new | (size_t)d_obs_term | (size_t)stage->d_o0 | (size_t)stage->d_o_next | (size_t)ring->d_o | (size_t)ring->d_o_next) % 4 == 0;
     (void)hipGetLastError();
-    if (dw)
-        hipLaunchKernelGGL((k_stream_step<uint32_t>), dim3((unsigned)n_envs), dim3(kStreamBlock), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
+    const bool coop = (long)episode_limit * (dw ? obs_row_bytes / 4 : obs_row_bytes) > kCoopMinWords;
+    if (dw && coop)
+        hipLaunchKernelGGL((k_stream_step<uint32_t, true>), dim3((unsigned)n_envs), dim3(kStreamBlock), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
                            episode_limit, ring->slots, obs_row_bytes / 4, hidden, (const uint32_t *)d_obs_prev, (const uint32_t *)d_obs_new,
                            (const uint32_t *)d_obs_term, d_term, d_team_reward, d_constraints, constraints_f64, d_success, t_in, t_out, (uint32_t *)stage->d_o0,
                            (uint32_t *)stage->d_o_next, stage->d_u, stage->d_onehot, stage->d_r, stage->d_ep_acc, stage->d_chip_acc,
                            stage->d_close_slot, rp, st_in, st_out, d_hidden, d_last_onehot, d_epsilon, anneal, min_epsilon, d_draw);
-    else
-        hipLaunchKernelGGL((k_stream_step<int8_t>), dim3((unsigned)n_envs), dim3(kStreamBlock), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
+    else if (dw)
+        hipLaunchKernelGGL((k_stream_step<uint32_t, false>), dim3((unsigned)n_envs), dim3(kStreamBlock), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
+                           episode_limit, ring->slots, obs_row_bytes / 4, hidden, (const uint32_t *)d_obs_prev, (const uint32_t *)d_obs_new,
+                           (const uint32_t *)d_obs_term, d_term, d_team_reward, d_constraints, constraints_f64, d_success, t_in, t_out, (uint32_t *)stage->d_o0,
+                           (uint32_t *)stage->d_o_next, stage->d_u, stage->d_onehot, stage->d_r, stage->d_ep_acc, stage->d_chip_acc,
+                           stage->d_close_slot, rp, st_in, st_out, d_hidden, d_last_onehot, d_epsilon, anneal, min_epsilon, d_draw);
+    else   // (byte rows: the shared form)
+        hipLaunchKernelGGL((k_stream_step<int8_t, true>), dim3((unsigned)n_envs), dim3(kStreamBlock), 0, (hipStream_t)stream, n_envs, n_agents, n_actions,
                            episode_limit, ring->slots, obs_row_bytes, hidden, d_obs_prev, d_obs_new, d_obs_term, d_term, d_team_reward, d_constraints,
                            constraints_f64, d_success, t_in, t_out, stage->d_o0, stage->d_o_next, stage->d_u, stage->d_onehot, stage->d_r,
                            stage->d_ep_acc, stage->d_chip_acc, stage->d_close_slot, rp, st_in, st_out, d_hidden, d_last_onehot, d_epsilon,
