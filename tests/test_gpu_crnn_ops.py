@@ -331,3 +331,20 @@ def test_front19_train_node_matches_torch_autograd(od, rows):
         err = _rel_l2(g.numpy(), r.numpy())
         print('front19 od=%d rows=%d %s rel_l2=%.2e' % (od, rows, name, err))
         assert err <= GRAD_TOL, (name, err)
+    # The rows left out above (a pre-activation within 2e-5 of zero: float32 and float64 may put its ReLU on different sides) are
+    # not skipped altogether: the same comparison with the upstream gradient on EVERY row.  A flipped ReLU moves a gradient by a
+    # whole term, so the bound is loose (a few flips among ~5000 activations per row), but an indexing or accumulation error in the
+    # rows masked above would show at order one.
+    for p in params:
+        p.grad = None
+    for p in ref.parameters():
+        p.grad = None
+    gall = torch.randn(rows, cols, device='cuda')
+    xall = _Front19Train.apply(obs, oh, c1.weight, c1.bias, c3.weight, c3.bias, net.mlp1.weight, net.mlp1.bias, cols)
+    (xall * gall).sum().backward()
+    (ref.features(inp) * gall[:, :nf].double().cpu()).sum().backward()
+    for name, p, r in zip(('w1', 'b1', 'w3', 'b3', 'mlp_w', 'mlp_b'), params,
+                          (r1.weight.grad, r1.bias.grad, r3.weight.grad, r3.bias.grad, ref.mlp1.weight.grad, ref.mlp1.bias.grad)):
+        err = _rel_l2(p.grad.detach().cpu().numpy(), r.numpy())
+        print('front19 od=%d rows=%d %s rel_l2 on all rows=%.2e' % (od, rows, name, err))
+        assert err <= 2e-2, (name, err)
