@@ -97,3 +97,52 @@ def test_against_live_reference_class():
         assert (mine.current_idx, mine.current_size) == (ref.current_idx, ref.current_size)
         for k in ref.buffers:
             assert np.array_equal(mine.buffers[k].numpy().astype(ref.buffers[k].dtype), ref.buffers[k]), (k, inc)
+
+
+def test_ring_bookkeeping_host_mirror_and_length_sorted_draw():
+    """The device-side ring bookkeeping the continuous rollout writes (include/rollout_ops.h: rollout_ring) is kept in step by
+    store_episode too; sync_host mirrors it in ONE read; draw picks filled slots uniformly with replacement
+    (common/replay_buffer.py:53) and hands them over sorted by episode length, longest first, with their lengths."""
+    a = _args(size=12)
+    a.seed = 3
+    buf = ReplayBuffer(a)
+    T = a.episode_limit
+    ep = _batch(0, 7, a)
+    lens = np.array([3, 1, 2, 3, 1, 1, 2])
+    ep['padded'] = np.arange(T)[None, :, None] >= lens[:, None, None]
+    ep['terminated'] = np.arange(T)[None, :, None] >= lens[:, None, None] - 1
+    buf.store_episode(ep)
+    extra = buf.sync_host(torch.tensor([5, 6, 7]))
+    assert extra == [5, 6, 7]
+    assert (buf.current_idx, buf.current_size) == (7, 7)
+    assert buf.host_len[:7].tolist() == lens.tolist() and not buf.host_len[7:].any()
+    assert buf.ring_state[:2].tolist() == [7, 7]
+    seen = set()
+    for _ in range(40):
+        idx, ln = buf.draw(5)
+        assert idx.shape == ln.shape == (5,) and (idx < 7).all() and (idx >= 0).all()
+        assert ln.tolist() == lens[idx].tolist() and (np.diff(ln) <= 0).all()      # longest first
+        seen.update(idx.tolist())
+        got = buf.gather(idx)
+        for k, v in got.items():
+            assert torch.equal(v, buf.buffers[k][torch.as_tensor(idx)])
+    assert seen == set(range(7))                                                     # every filled slot is reachable, no empty one
+    # the ring wraps: lengths of the overwritten slots follow
+    ep2 = _batch(7, 8, a)
+    ep2['padded'] = np.zeros((8, T, 1), bool)
+    buf.store_episode(ep2)
+    buf.sync_host()
+    assert buf.current_size == 12 and buf.host_len.tolist() == [3, 3, 3] + lens[3:].tolist() + [3] * 5
+
+
+def test_pack_units_lists_the_valid_steps_step_after_step():
+    """VDN.pack_units (host side of learn_packed): counts[t] = episodes longer than t; units = slot * T + t of those episodes,
+    step 0 first -- the layout of gru_seq_forward_packed / vdn_td_forward_packed (include/crnn_ops.h, include/vdn_ops.h)."""
+    from marl_dmfb_amd.policy.vdn import VDN
+    idx = np.array([9, 2, 5, 7])          # sorted by length, longest first
+    lens = np.array([4, 2, 2, 1])
+    counts, units = VDN.pack_units(idx, lens, 10)
+    assert counts.tolist() == [4, 3, 1, 1]
+    assert units.dtype == np.int32
+    assert units.tolist() == [90, 20, 50, 70, 91, 21, 51, 92, 93]
+    assert len(units) == lens.sum()
