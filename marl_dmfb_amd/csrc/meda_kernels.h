@@ -71,8 +71,10 @@ __device__ __forceinline__ int d2(int ax, int ay, int bx, int by) { return (ax -
 
 // ---- task generation: addTask x n (meda.py:175-185), serial like the reference ---------------------
 template <int N>
-__device__ __noinline__ void gen_task(const MCfg &c, uint32_t gid, uint32_t ep, int (&sx)[N], int (&sy)[N],
+__device__ __noinline__ void gen_task(uint32_t k0, uint32_t k1, int W, int L, uint32_t gid, uint32_t ep, int (&sx)[N], int (&sy)[N],
                                       int (&gx)[N], int (&gy)[N]) {
+    // (the configuration comes in as scalars: a reference to the kernel's by-value MCfg made every lane copy the struct into scratch
+    // memory at kernel entry -- 64 B of stores per chip-step in k_meda_step whether or not a task was generated)
     // Rare path (once per episode): kept as ROLLED loops over private arrays on purpose -- fully
     // unrolling the nested rejection loops makes the compile time explode for N = 9..15.
     int lx[2][N], ly[2][N];  // [0] droplets, [1] destinations
@@ -84,10 +86,10 @@ __device__ __noinline__ void gen_task(const MCfg &c, uint32_t gid, uint32_t ep, 
 #pragma unroll 1
             for (;;) {
                 uint32_t w[4];  // getRandomYX (meda.py:224-227)
-                philox(c.k0, c.k1, gid, ep, k, STREAM_MEDA_TASK << 8, w);
+                philox(k0, k1, gid, ep, k, STREAM_MEDA_TASK << 8, w);
                 ++k;
-                const int y = kR + below(w[0], c.W - 2 * kR);
-                const int x = kR + below(w[1], c.L - 2 * kR);
+                const int y = kR + below(w[0], W - 2 * kR);
+                const int x = kR + below(w[1], L - 2 * kR);
                 bool ok = true;  // _genLegalDroplet: not closer than 9 to an earlier box of the same list
 #pragma unroll 1
                 for (int j = 0; j < i; ++j) ok &= d2(x, y, lx[which][j], ly[which][j]) >= 81;
@@ -270,23 +272,36 @@ __global__ __launch_bounds__(kBlock) void k_meda_step(MCfg c, MPtrs p, MStepArgs
         a.out.d_team_reward[e] = s / (double)N;
     }
     if (term && (a.flags & MEDA_STEP_AUTORESET)) {  // MEDAEnv.reset() inside the launch (meda.py:541-550)
-        int sx[N], sy[N];
-        gen_task<N>(c, c.env_id0 + (uint32_t)e, rep, sx, sy, gx, gy);
+        // gen_task is a real call taking its four arrays by reference: they live in scratch memory.  Handing it gx / gy themselves
+        // put the GOALS OF EVERY TRANSITION there (224 B of scratch per lane: 96 B of extra WRITE_SIZE and 36 B of FETCH_SIZE per
+        // chip-step, tools/probe/meda_step_writes.py); with arrays of its own only a lane that resets touches scratch.
+        int sx[N], sy[N], tgx[N], tgy[N];
+        gen_task<N>(c.k0, c.k1, c.W, c.L, c.env_id0 + (uint32_t)e, rep, sx, sy, tgx, tgy);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
+            gx[i] = tgx[i]; gy[i] = tgy[i];
             cx[i] = sx[i]; cy[i] = sy[i];
             p.starts[(size_t)i * E + e] = (uint32_t)sx[i] | ((uint32_t)sy[i] << 8);
         }
         rep += 1; step = 0; failed = 0; status = 0;
         if (p.reset_flag) p.reset_flag[e] = 1;
     }
+    // WHOLE words go back: the compiler sees that a droplet word's goal half (and the `failed` half of the step word) is the value
+    // it loaded and would store the changed 16 bits alone (global_store_short).  A wave of 2-byte stores leaves every 32-byte
+    // sector half dirty; the L2 then fills and writes back whole lines for them: the record cost 128 B of WRITE_SIZE per chip-step
+    // instead of 32 and doubled the kernel's FETCH_SIZE (tools/probe/meda_step_writes.py).  The empty asm makes each word opaque.
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-        p.st[(size_t)i * E + e] = (uint32_t)cx[i] | ((uint32_t)cy[i] << 8) | ((uint32_t)gx[i] << 16) | ((uint32_t)gy[i] << 24);
+    for (int i = 0; i < N; ++i) {
+        uint32_t w = (uint32_t)cx[i] | ((uint32_t)cy[i] << 8) | ((uint32_t)gx[i] << 16) | ((uint32_t)gy[i] << 24);
+        asm volatile("" : "+v"(w));
+        p.st[(size_t)i * E + e] = w;
+    }
+    uint32_t sw2 = (step & 0xffff) | (failed << 16);
+    asm volatile("" : "+v"(sw2));
     p.st[(size_t)N * E + e] = status;
-    p.st[(size_t)(N + 1) * E + e] = (step & 0xffff) | (failed << 16);
+    p.st[(size_t)(N + 1) * E + e] = sw2;
     p.st[(size_t)(N + 2) * E + e] = rstep;
-    p.st[(size_t)(N + 3) * E + e] = rep;
+    if (term && (a.flags & MEDA_STEP_AUTORESET)) p.st[(size_t)(N + 3) * E + e] = rep;   // rng_ep changes only with a new task
 }
 
 // mode 0: reset()  2: restart()  3: create
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_meda_reset(MCfg c, MPtrs p, const ui
     }
     const uint32_t rep = mode == 3 ? 0u : p.st[(size_t)(N + 3) * E + e];
     int sx[N], sy[N], gx[N], gy[N];
-    gen_task<N>(c, c.env_id0 + (uint32_t)e, rep, sx, sy, gx, gy);
+    gen_task<N>(c.k0, c.k1, c.W, c.L, c.env_id0 + (uint32_t)e, rep, sx, sy, gx, gy);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         p.starts[(size_t)i * E + e] = (uint32_t)sx[i] | ((uint32_t)sy[i] << 8);
