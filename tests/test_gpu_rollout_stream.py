@@ -37,11 +37,15 @@ def _make(W, n, E, seed, buffer_size, trained=False, b_degrade=False, **over):
     return env, args, agents, worker, ReplayBuffer(args, device='cuda:0')
 
 
-def _oracle_episodes(cfg, E, seed, steps, T, n, O, A=5):
+def _oracle_episodes(cfg, E, seed, steps, T, n, O, A=5, meda=False):
     """Replay the recorded (lock-step -> actions) through the CPU oracle; returns the closed episodes in closing order
     (lock-step, then chip) as padded dicts + generate_episode's return values."""
-    from oracle.dmfb_oracle import DmfbOracle  # the checker
-    ora = DmfbOracle(n_envs=E, seed=seed, **cfg)
+    if meda:
+        from oracle.meda_oracle import MedaOracle  # the checker
+        ora = MedaOracle(n_envs=E, seed=seed, **cfg)
+    else:
+        from oracle.dmfb_oracle import DmfbOracle  # the checker
+        ora = DmfbOracle(n_envs=E, seed=seed, **cfg)
     ora.reset()
     obs = ora.observe()
     open_eps = [dict(o=[], u=[], r=[], o_next=[], cons=0, succ=0) for _ in range(E)]
@@ -55,7 +59,7 @@ def _oracle_episodes(cfg, E, seed, steps, T, n, O, A=5):
             ep = open_eps[e]
             ep['o'].append(obs[e].copy()); ep['o_next'].append(nxt[e].copy()); ep['u'].append(acts[e].copy())
             ep['r'].append(np.sum(rew[e]) / n)           # rollout.py:33 (numpy's summation order)
-            ep['cons'] += int(cons[e]); ep['succ'] += int(succ[e])
+            ep['cons'] += (float(cons[e]) if meda else int(cons[e])); ep['succ'] += int(succ[e])   # MEDA: the (float) sum of punishments
             if term[e]:
                 ln = len(ep['r'])
                 d = {'o': np.zeros((T, n, O), np.int8), 'o_next': np.zeros((T, n, O), np.int8), 'u': np.zeros((T, n, 1), np.int8),
@@ -164,3 +168,39 @@ def test_trainer_in_stream_mode_learns_and_counts():
     assert tr.buffer.current_size == 8 * E and int(tr.buffer.ring_state[2]) == tr.buffer.host_closed
     tr.collect_and_learn()   # the evaluation reset every chip: the stream restarts cleanly
     assert tr.last_round['played'] == E * 40
+
+
+def test_stream_episodes_replay_through_the_meda_oracle():
+    """The same for MEDA (30x30, 4 droplets, v0_2 observation, fov-19 network: 4 340-byte rows, episodes of 60 steps closed by all
+    workgroups together; the env has no terminal-observation output, so the reset follows the stream step as its own call)."""
+    from marl_dmfb_amd.agent.agent import Agents
+    from marl_dmfb_amd.common.arguments import make_args
+    from marl_dmfb_amd.common.replay_buffer import ReplayBuffer
+    from marl_dmfb_amd.common.rollout import RolloutWorker
+    from marl_dmfb_amd.env.meda import VecMEDA
+    W, n, E, K, seed = 30, 4, 20, 150, 3
+    env = VecMEDA(W, W, n, fov=19, n_envs=E, seed=seed, device='cuda:0', version=2)
+    args = make_args(name='meda', drop_num=n, width=W, length=W, fov=19, device='cuda:0', n_envs=E, buffer_size=256, **env.get_env_info())
+    torch.manual_seed(seed)
+    worker = RolloutWorker(env, Agents(args), args)
+    buf = ReplayBuffer(args, device='cuda:0')
+    assert worker.stream_ok()
+    worker.epsilon = torch.tensor(1.0, device='cuda:0')
+    worker.anneal_epsilon, worker.min_epsilon = 0.0, 0.0
+    T, O, A = args.episode_limit, env.obs_len, args.n_actions
+    steps = []
+    worker.stream_step_hook = lambda s, a, term: steps.append((a.cpu().numpy().copy(), term.cpu().numpy().copy()))
+    acc = np.zeros(4, np.int64)
+    for chunk in (K // 2, K - K // 2):
+        acc += np.asarray(buf.sync_host(worker.generate_steps(buf, chunk)))
+    want = _oracle_episodes(dict(width=W, length=W, n_agents=n, fov=19, version=2), E, seed, steps, T, n, O, A=A, meda=True)
+    assert len(want) == buf.host_closed == acc[0] >= 2 * E
+    lens = np.array([d['len'] for d in want])
+    assert (lens < T).sum() >= 1, lens
+    np.testing.assert_array_equal(buf.host_len[:len(want)], lens)
+    got = {k: buf.buffers[k][:len(want)].cpu().numpy() for k in KEYS}
+    stats = buf.ring_stats[:len(want)].cpu().numpy()
+    for k, d in enumerate(want):
+        for key in KEYS:
+            np.testing.assert_array_equal(got[key][k].reshape(d[key].shape), d[key], err_msg='slot %d key %s (len %d)' % (k, key, d['len']))
+        np.testing.assert_array_equal(stats[k].view(np.int64), np.asarray(d['stats'], np.float64).view(np.int64), err_msg='stats of slot %d' % k)
