@@ -78,6 +78,15 @@ int crnn_conv9_backward_parts(int od);
 int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, const float *d_out, int64_t out_stride,
                         const float *d_grad_out, int64_t grad_stride, const float *d_w1, const float *d_b1, const float *d_w2,
                         int od, float *d_part, int n_part, float *d_grads, void *stream);
+/* Gradients of the vector branch relu(mlp1([dir_x, dir_y, last-action one-hot])) of the GRU input row (network/base_net.py:66,
+ * backward of policy/vdn.py:123-128): d_grad_w float32[10][2 + n_actions], d_grad_b float32[10].  d_out / d_grad_out are the
+ * forward's output rows (crnn_front9_forward / crnn_front19_forward) and the gradient w.r.t. them; the branch's ten columns
+ * start at col0 (od*25).  The direction bytes are d_obs[row*obs_stride + dir_offset .. +1] (243 for fov 9, 1083 for fov 19).
+ * d_part: scratch float32[crnn_mlp_backward_parts()].  Two launches; sums in a fixed order (deterministic). */
+int crnn_mlp_backward_parts(void);
+int crnn_mlp_backward(const int8_t *d_obs, int64_t obs_stride, int dir_offset, const int8_t *d_onehot, int n_actions, int64_t rows,
+                      const float *d_out, int64_t out_stride, const float *d_grad_out, int64_t grad_stride, int col0, float *d_part,
+                      float *d_grad_w, float *d_grad_b, void *stream);
 /* Gradients of the fov-19 conv stack (conv_str(19) of network/base_net.py:23-33: stride-2 conv1, then the tied conv3 twice) for
  * the eval network of VDN.learn on MEDA: d_out = crnn_front19_forward's output (its sign is the last ReLU's mask), d_grad_out the
  * gradient w.r.t. it (only the first od*25 columns of a row are read).  Nothing is saved by the forward: a1 and a2 of each row

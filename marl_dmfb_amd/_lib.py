@@ -155,6 +155,8 @@ def crnn_ops():
     lib.crnn_front_padded_cols.argtypes = [C.c_int]
     lib.crnn_conv9_backward_parts.argtypes = [C.c_int]
     lib.crnn_conv9_backward.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
+    lib.crnn_mlp_backward_parts.argtypes = []
+    lib.crnn_mlp_backward.argtypes = [vp, i64, C.c_int, vp, C.c_int, i64, vp, i64, vp, i64, C.c_int, vp, vp, vp, vp]
     lib.crnn_conv19_backward_parts.argtypes = [C.c_int]
     lib.crnn_conv19_backward.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
     lib.crnn_last_hip_error.argtypes = []

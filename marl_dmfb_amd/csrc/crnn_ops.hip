@@ -460,6 +460,63 @@ __global__ __launch_bounds__(64 * kRedY) void k_conv9_bwd_reduce(const float *__
     }
 }
 
+// ---- backward of the vector branch relu(mlp1([dir_x, dir_y, last-action one-hot])) (network/base_net.py:66): dW [10][nin], db [10]
+// from the gradient / the forward's output columns of the branch and the int8 inputs.  Thread = row (grid-stride), 10 * nin + 10
+// sums in registers, added over the workgroup through LDS in a fixed order, one partial vector per workgroup; the last launch adds
+// the partial vectors (fixed order: deterministic).  81 920 rows: 7 MB of reads, two launches, against eleven torch launches.
+constexpr int kMlpBlock = 256, kMlpOut = 10, kMlpMaxIn = 18, kMlpMaxParts = 256;
+__global__ __launch_bounds__(kMlpBlock) void k_mlp_bwd(const int8_t *__restrict__ obs, long obs_stride, int dir_off,
+                                                       const int8_t *__restrict__ onehot, int n_actions, long rows,
+                                                       const float *__restrict__ x, long x_stride, const float *__restrict__ g, long g_stride,
+                                                       int col0, float *__restrict__ part) {
+    __shared__ float s_red[kMlpBlock / 64][kMlpOut * (kMlpMaxIn + 1)];
+    float acc[kMlpOut][kMlpMaxIn + 1];   // [o][k < nin] = dW, [o][kMlpMaxIn] = db
+#pragma unroll
+    for (int o = 0; o < kMlpOut; ++o)
+#pragma unroll
+        for (int k = 0; k <= kMlpMaxIn; ++k) acc[o][k] = 0.0f;
+    for (long r = (long)blockIdx.x * kMlpBlock + threadIdx.x; r < rows; r += (long)gridDim.x * kMlpBlock) {
+        float v[kMlpMaxIn];
+        v[0] = (float)obs[r * obs_stride + dir_off];
+        v[1] = (float)obs[r * obs_stride + dir_off + 1];
+#pragma unroll
+        for (int k = 0; k < kMlpMaxIn - 2; ++k) v[2 + k] = k < n_actions ? (float)onehot[r * n_actions + k] : 0.0f;
+#pragma unroll
+        for (int o = 0; o < kMlpOut; ++o) {
+            const float gz = x[r * x_stride + col0 + o] > 0.0f ? g[r * g_stride + col0 + o] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < kMlpMaxIn; ++k) acc[o][k] = fmaf(gz, v[k], acc[o][k]);
+            acc[o][kMlpMaxIn] += gz;
+        }
+    }
+    // wave sums (shuffles), then the four waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 0; o < kMlpOut; ++o)
+#pragma unroll
+        for (int k = 0; k <= kMlpMaxIn; ++k) {
+            float t = acc[o][k];
+            for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d);
+            if (lane == 0) s_red[wave][o * (kMlpMaxIn + 1) + k] = t;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kMlpOut * (kMlpMaxIn + 1); i += kMlpBlock) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kMlpBlock / 64; ++w) t += s_red[w][i];
+        part[(size_t)blockIdx.x * kMlpOut * (kMlpMaxIn + 1) + i] = t;
+    }
+}
+__global__ __launch_bounds__(256) void k_mlp_bwd_reduce(const float *__restrict__ part, int n_part, int nin, float *__restrict__ dw, float *__restrict__ db) {
+    const int i = threadIdx.x;   // one thread per output: 10 * nin weights, then 10 biases
+    if (i >= kMlpOut * nin + kMlpOut) return;
+    const int o = i < kMlpOut * nin ? i / nin : i - kMlpOut * nin, k = i < kMlpOut * nin ? i - o * nin : kMlpMaxIn;
+    float t = 0.0f;
+    for (int b = 0; b < n_part; ++b) t += part[(size_t)b * kMlpOut * (kMlpMaxIn + 1) + o * (kMlpMaxIn + 1) + k];
+    if (i < kMlpOut * nin) dw[i] = t;
+    else db[o] = t;
+}
+
 thread_local int g_last_hip = 0;
 
 // The dynamic-LDS limit is an attribute of the function ON ONE DEVICE: remember per device whether it has been raised
@@ -649,6 +706,26 @@ int crnn_conv9_backward(const int8_t *d_obs, int64_t obs_stride, int64_t rows, c
     if (od == 24) return launch_bwd<24>(d_obs, obs_stride, rows, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, d_w1, d_b1, (hipStream_t)stream);
     if (od == 32) return launch_bwd<32>(d_obs, obs_stride, rows, d_out, out_stride, d_grad_out, grad_stride, d_w2, d_part, n_part, d_grads, d_w1, d_b1, (hipStream_t)stream);
     return CRNN_ERR_UNSUPPORTED;
+}
+
+int crnn_mlp_backward_parts(void) { return kMlpMaxParts * kMlpOut * (kMlpMaxIn + 1); }
+
+int crnn_mlp_backward(const int8_t *d_obs, int64_t obs_stride, int dir_offset, const int8_t *d_onehot, int n_actions, int64_t rows,
+                      const float *d_out, int64_t out_stride, const float *d_grad_out, int64_t grad_stride, int col0, float *d_part,
+                      float *d_grad_w, float *d_grad_b, void *stream) {
+    if (!d_obs || !d_onehot || !d_out || !d_grad_out || !d_part || !d_grad_w || !d_grad_b || rows <= 0 || n_actions < 0 ||
+        n_actions > kMlpMaxIn - 2 || dir_offset < 0 || obs_stride < dir_offset + 2 || col0 < 0 || out_stride < col0 + kMlpOut ||
+        grad_stride < col0 + kMlpOut)
+        return CRNN_ERR_BAD_ARG;
+    const long want = (rows + kMlpBlock - 1) / kMlpBlock;
+    const int grid = (int)(want < kMlpMaxParts ? want : kMlpMaxParts);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_mlp_bwd, dim3(grid), dim3(kMlpBlock), 0, (hipStream_t)stream, d_obs, (long)obs_stride, dir_offset, d_onehot, n_actions,
+                       (long)rows, d_out, (long)out_stride, d_grad_out, (long)grad_stride, col0, d_part);
+    hipLaunchKernelGGL(k_mlp_bwd_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, d_part, grid, 2 + n_actions, d_grad_w, d_grad_b);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip = (int)e; return CRNN_ERR_HIP; }
+    return CRNN_OK;
 }
 
 int crnn_conv19_backward_parts(int od) { return od == 24 ? crnn_bwd19::GeoB19<24>::PART : od == 32 ? crnn_bwd19::GeoB19<32>::PART : CRNN_ERR_UNSUPPORTED; }

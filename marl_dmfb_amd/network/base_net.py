@@ -68,6 +68,27 @@ def _conv9_backward(obs_i8, x, g, w1c, b1c, w2c, od):
     return tot
 
 
+def _mlp_branch_backward(obs_i8, dir_off, onehot_i8, x, g, col0):
+    """(dW [10][2 + A], db [10]) of the vector branch relu(mlp1([dir, last action])) from the gradient / output columns
+    col0 .. col0+9 of the GRU input rows (include/crnn_ops.h: crnn_mlp_backward; two launches)."""
+    import ctypes as C
+    from .. import _lib
+    lib = _lib.crnn_ops()
+    vp = C.c_void_p
+    A = onehot_i8.shape[1]
+    if g.stride(1) != 1:
+        g = g.contiguous()
+    g_w = torch.empty((10, 2 + A), dtype=torch.float32, device=g.device)
+    g_b = torch.empty((10,), dtype=torch.float32, device=g.device)
+    part = torch.empty((lib.crnn_mlp_backward_parts(),), dtype=torch.float32, device=g.device)
+    rc = lib.crnn_mlp_backward(vp(obs_i8.data_ptr()), obs_i8.stride(0), dir_off, vp(onehot_i8.data_ptr()), A, obs_i8.shape[0],
+                               vp(x.data_ptr()), x.stride(0), vp(g.data_ptr()), g.stride(0), col0, vp(part.data_ptr()),
+                               vp(g_w.data_ptr()), vp(g_b.data_ptr()), vp(torch.cuda.current_stream(g.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError('crnn_mlp_backward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
+    return g_w, g_b
+
+
 class _ConvFront9(torch.autograd.Function):
     """conv1+ReLU+conv2+ReLU of int8 observation rows for fov 9 through the hand-written HIP kernels
     (include/crnn_ops.h: crnn_conv9_forward / crnn_conv9_backward), with gradients for the four parameter tensors.
@@ -134,11 +155,9 @@ class _Front9Train(torch.autograd.Function):
         od = s1[0]
         n2 = od * od * 9
         tot = _conv9_backward(obs_i8, x, g, w1c, b1c, w2c, od)
-        gz = g[:, od * 25:od * 25 + 10] * (x[:, od * 25:od * 25 + 10] > 0)
-        vec = torch.cat([obs_i8[:, 243:245].float(), onehot_i8.float()], dim=1)
-        g_mw = _wgrad_splitk(gz.contiguous(), vec)
+        g_mw, g_mb = _mlp_branch_backward(obs_i8, 243, onehot_i8, x, g, od * 25)
         return (None, None, tot[n2 + od:n2 + od + od * 27].view(s1), tot[n2 + od + od * 27:], tot[:n2].view(s2), tot[n2:n2 + od],
-                g_mw, _colsum(gz), None)
+                g_mw, g_mb, None)
 
 
 class _Front19Train(torch.autograd.Function):
@@ -187,11 +206,9 @@ class _Front19Train(torch.autograd.Function):
                                       vp(part.data_ptr()), N_PART, vp(tot.data_ptr()), vp(torch.cuda.current_stream(g.device).cuda_stream))
         if rc != 0:
             raise RuntimeError('crnn_conv19_backward failed: %d (hip %d)' % (rc, lib.crnn_last_hip_error()))
-        gz = g[:, od * 25:od * 25 + 10] * (x[:, od * 25:od * 25 + 10] > 0)
-        vec = torch.cat([obs_i8[:, 1083:1085].float(), onehot_i8.float()], dim=1)
-        g_mw = _wgrad_splitk(gz.contiguous(), vec)
+        g_mw, g_mb = _mlp_branch_backward(obs_i8, 1083, onehot_i8, x, g, od * 25)
         return (None, None, tot[n3 + od:n3 + od + od * 27].view(s1), tot[n3 + od + od * 27:], tot[:n3].view(s3), tot[n3:n3 + od],
-                g_mw, _colsum(gz), None)
+                g_mw, g_mb, None)
 
 
 class _LinearSplitK(torch.autograd.Function):

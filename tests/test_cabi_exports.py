@@ -86,7 +86,7 @@ def test_crnn_ops_library_exports():
     names = sorted(set(re.findall(r'\b(crnn_[a-z_0-9]+)\s*\(', txt)))
     assert names == ['crnn_conv19_backward', 'crnn_conv19_backward_parts', 'crnn_conv9_backward', 'crnn_conv9_backward_parts', 'crnn_conv9_forward', 'crnn_front19_forward',
                      'crnn_front9_forward', 'crnn_front9_forward_live',
-                     'crnn_front_padded_cols', 'crnn_last_hip_error']
+                     'crnn_front_padded_cols', 'crnn_last_hip_error', 'crnn_mlp_backward', 'crnn_mlp_backward_parts']
     gru = sorted(set(re.findall(r'\b(gru_[a-z_0-9]+)\s*\(', txt)))
     assert gru == ['gru_last_hip_error', 'gru_seq_backward', 'gru_seq_backward_packed', 'gru_seq_forward', 'gru_seq_forward_packed',
                    'gru_seq_row_blocks']
