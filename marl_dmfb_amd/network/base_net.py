@@ -126,7 +126,7 @@ class _ConvFront9(torch.autograd.Function):
 class _Front9Train(torch.autograd.Function):
     """The whole GRU input row x = cat([conv features, relu(mlp1([dir, last action]))]) of the eval network in ONE
     launch (crnn_front9_forward) with a hand-written backward: crnn_conv9_backward for the four conv tensors (reading
-    the row-strided gradient in place, recomputing conv1) and two small split-K GEMMs for mlp1."""
+    the row-strided gradient in place, recomputing conv1) and crnn_mlp_backward for mlp1."""
 
     @staticmethod
     def forward(ctx, obs_i8, onehot_i8, w1, b1, w2, b2, mlp_w, mlp_b, cols):
@@ -164,7 +164,7 @@ class _Front19Train(torch.autograd.Function):
     """The GRU input row of the eval network for fov 19 (MEDA): x = cat([conv features, relu(mlp1([dir, last action]))]) in ONE
     launch (crnn_front19_forward: stride-2 conv1, then the tied conv3 twice) with a hand-written backward
     (crnn_conv19_backward: recomputes a1 / a2 on the matrix cores, transposed convolutions in gather form, both applications of
-    conv3 add into one weight gradient) and two small split-K GEMMs for mlp1."""
+    conv3 add into one weight gradient) and crnn_mlp_backward for mlp1."""
 
     @staticmethod
     def forward(ctx, obs_i8, onehot_i8, w1, b1, w3, b3, mlp_w, mlp_b, cols):
