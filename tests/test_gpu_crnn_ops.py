@@ -348,3 +348,41 @@ def test_front19_train_node_matches_torch_autograd(od, rows):
         err = _rel_l2(p.grad.detach().cpu().numpy(), r.numpy())
         print('front19 od=%d rows=%d %s rel_l2 on all rows=%.2e' % (od, rows, name, err))
         assert err <= 2e-2, (name, err)
+
+
+@pytest.mark.parametrize('rows,A,dir_off,col0,pad', [(1, 5, 243, 600, 0), (257, 3, 243, 600, 30), (70001, 16, 1083, 800, 22), (4096, 0, 243, 600, 0)])
+def test_mlp_branch_backward_matches_float64(rows, A, dir_off, col0, pad):
+    """crnn_mlp_backward (gradients of relu(mlp1([dir, last action])), network/base_net.py:66) against float64 tensor ops: ragged row
+    counts, 0..16 actions, both direction-byte offsets, row-strided x / gradient with a zero-padded tail."""
+    import ctypes as C
+    from marl_dmfb_amd import _lib
+    lib = _lib.crnn_ops()
+    vp = C.c_void_p
+    g = torch.Generator(device='cuda').manual_seed(rows + A)
+    obs = torch.randint(-4, 5, (rows, dir_off + 2), dtype=torch.int8, device='cuda', generator=g)
+    onehot = torch.zeros((rows, max(A, 1)), dtype=torch.int8, device='cuda')
+    if A:
+        onehot[torch.arange(rows, device='cuda'), torch.randint(0, A, (rows,), device='cuda', generator=g)] = 1
+    onehot = onehot[:, :A].contiguous() if A else onehot[:, :0].contiguous()
+    cols = col0 + 10 + pad
+    x = torch.randn((rows, cols), device='cuda', generator=g)
+    x[:, col0:col0 + 10] = torch.relu(x[:, col0:col0 + 10])       # what the forward leaves: post-ReLU values (zeros where clipped)
+    grad = torch.randn((rows, cols), device='cuda', generator=g)
+    g_w = torch.full((10, 2 + A), 7.0, device='cuda')
+    g_b = torch.full((10,), 7.0, device='cuda')
+    part = torch.empty((lib.crnn_mlp_backward_parts(),), device='cuda')
+    oh_ptr = vp(onehot.data_ptr()) if A else vp(obs.data_ptr())      # never read when n_actions == 0, but must not be NULL
+    rc = lib.crnn_mlp_backward(vp(obs.data_ptr()), obs.stride(0), dir_off, oh_ptr, A, rows, vp(x.data_ptr()), x.stride(0),
+                               vp(grad.data_ptr()), grad.stride(0), col0, vp(part.data_ptr()), vp(g_w.data_ptr()), vp(g_b.data_ptr()), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    gz = (grad[:, col0:col0 + 10] * (x[:, col0:col0 + 10] > 0)).double()
+    vec = torch.cat([obs[:, dir_off:dir_off + 2].double(), onehot.double()], dim=1)
+    want_w, want_b = gz.t() @ vec, gz.sum(0)
+    assert _rel_l2(g_w.cpu().numpy(), want_w.cpu().numpy()) <= GRAD_TOL
+    assert _rel_l2(g_b.cpu().numpy(), want_b.cpu().numpy()) <= GRAD_TOL
+    # argument checks: too many actions, a row too short for the branch's columns
+    assert lib.crnn_mlp_backward(vp(obs.data_ptr()), obs.stride(0), dir_off, oh_ptr, 17, rows, vp(x.data_ptr()), x.stride(0),
+                                 vp(grad.data_ptr()), grad.stride(0), col0, vp(part.data_ptr()), vp(g_w.data_ptr()), vp(g_b.data_ptr()), None) != 0
+    assert lib.crnn_mlp_backward(vp(obs.data_ptr()), obs.stride(0), dir_off, oh_ptr, A, rows, vp(x.data_ptr()), col0 + 9,
+                                 vp(grad.data_ptr()), grad.stride(0), col0, vp(part.data_ptr()), vp(g_w.data_ptr()), vp(g_b.data_ptr()), None) != 0
