@@ -130,6 +130,15 @@ int gru_seq_backward(const float *d_grad_hs, const float *d_gates, const float *
 #define GRU_SEQ_MAX_STEPS 255
 int gru_seq_forward_packed(const float *d_igates, const float *d_h0, const float *d_w_hh, const float *d_b_ih, const float *d_b_hh,
                            int T, int64_t R, int hidden, const int32_t *step_rows, float *d_hs, float *d_gates, void *stream);
+/* gru_seq_forward_packed for ONE or TWO networks over the same packed batch in one launch (the eval and the target network of
+ * VDN.learn, policy/vdn.py:174-191): the recurrence h W_hh^T runs on the matrix cores, 16 rows per workgroup, so that the two
+ * networks' 2 x R/16 workgroups fill the GPU where one network's R/8 did (csrc/gru_ops.hip).  Network b is skipped when
+ * d_igates_b is NULL.  d_h0_* NULL = zero initial state; d_gates_* NULL = gates not saved (no backward).  Outputs as
+ * gru_seq_forward_packed (same layouts: gru_seq_backward_packed takes them); sums in another order: values agree to rounding. */
+int gru_seq_forward_packed_pair(const float *d_igates_a, const float *d_h0_a, const float *d_w_hh_a, const float *d_b_ih_a,
+                                const float *d_b_hh_a, float *d_hs_a, float *d_gates_a, const float *d_igates_b, const float *d_h0_b,
+                                const float *d_w_hh_b, const float *d_b_ih_b, const float *d_b_hh_b, float *d_hs_b, float *d_gates_b,
+                                int T, int64_t R, int hidden, const int32_t *step_rows, void *stream);
 int gru_seq_backward_packed(const float *d_grad_hs, const float *d_gates, const float *d_hs, const float *d_h0, const float *d_w_hh,
                             int T, int64_t R, int hidden, const int32_t *step_rows, float *d_d_igates, float *d_d_hgates,
                             float *d_d_h0, float *d_bias_part, float *d_h_prev, void *stream);

@@ -164,6 +164,7 @@ def crnn_ops():
     lib.gru_seq_backward.argtypes = [vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, vp, vp, vp, vp, vp]
     ip = C.POINTER(C.c_int32)
     lib.gru_seq_forward_packed.argtypes = [vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, ip, vp, vp, vp]
+    lib.gru_seq_forward_packed_pair.argtypes = [vp] * 14 + [C.c_int, i64, C.c_int, ip, vp]
     lib.gru_seq_backward_packed.argtypes = [vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, ip, vp, vp, vp, vp, vp, vp]
     lib.gru_seq_row_blocks.argtypes = [i64]
     lib.gru_seq_row_blocks.restype = i64

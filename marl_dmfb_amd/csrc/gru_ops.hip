@@ -234,6 +234,99 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
     }
 }
 
+// ---- forward on the matrix cores, eval and target network in ONE launch (the packed learn of VDN.learn) ----------------------
+// k_gru_seq_fwd gives 8 rows to a workgroup because its VALU dot products need the k-quarters' partial sums exchanged through LDS;
+// 2048 sequences then fill the 256 CUs once, and the eval and the target network (two launches) each pay T steps of ~3.6 µs.
+// On the matrix cores a workgroup takes 16 rows (the M of v_mfma_f32_16x16x4_f32): wave w owns hidden units 16 w .. 16 w + 15 of all
+// three gates (three column tiles: the r / z / n values of a (row, unit) pair land in the same lane), keeps its 3 x 16 x 128 slice of
+// W_hh in 96 registers as the B operands, reads h (16 x 128, LDS) as the A operand with eight 16-byte reads per step (K order: a
+// lane quarter holds k = 16 jj + 4 kq + c), and finishes its own gates: no partial sums, ONE barrier per step (h double-buffered).
+// 2048 sequences are 128 workgroups; the two networks of a learn make 256 -- one launch, every CU busy, ~the time one network took.
+constexpr int kMW = 16, kMHS = 132;   // rows per workgroup; LDS row stride of h (= 4 mod 32: the 16 lanes of a read group cover all banks)
+struct GruNetIO {
+    const float *igates, *h0, *w_hh, *b_ih, *b_hh;   // h0 NULL = zeros
+    float *hs, *gates;                               // gates NULL = not saved
+};
+__global__ __launch_bounds__(kBlock) void k_gru_seq_fwd_mfma(GruNetIO n0, GruNetIO n1, int blocks_per_net, int T, long R, const SeqOff so) {
+    __shared__ __attribute__((aligned(16))) float s_h[2][kMW][kMHS];
+    const bool second = (int)blockIdx.x >= blocks_per_net;
+    const GruNetIO io = second ? n1 : n0;
+    const long row0 = (long)((int)blockIdx.x - (second ? blocks_per_net : 0)) * kMW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const int u = 16 * wave + j;   // this lane's hidden unit (B column / D column)
+    const int rv = (int)min((long)kMW, R - row0);
+    f32x4 bw[3][8];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) bw[g][jj] = *(const f32x4 *)(io.w_hh + (size_t)(g * H + u) * H + 16 * jj + 4 * kq);
+    const float bir = io.b_ih[u] + io.b_hh[u], biz = io.b_ih[H + u] + io.b_hh[H + u], bin = io.b_ih[2 * H + u], bhn = io.b_hh[2 * H + u];
+    for (int i = tid; i < kMW * H; i += kBlock) {
+        const int rr = i / H, c = i - rr * H;
+        s_h[0][rr][c] = (rr < rv && io.h0) ? io.h0[(row0 + rr) * H + c] : 0.0f;
+        s_h[1][rr][c] = 0.0f;   // rows past the end / ended sequences: finite values on the A side, results never stored
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const long rt = so.packed ? (long)(so.off[t + 1] - so.off[t]) : R;
+        if (row0 >= rt) break;  // uniform: lengths only shrink along the rows
+        const int rvt = (int)min((long)rv, rt - row0);
+        const size_t base = (so.packed ? (size_t)so.off[t] : (size_t)t * R) + (size_t)row0;
+        const float (*cur)[kMHS] = s_h[t & 1];
+        float (*nxt)[kMHS] = s_h[(t + 1) & 1];
+        // x-side gates of my four rows (D rows 4 kq + q): issued first, consumed after the MFMAs
+        float ig[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = 4 * kq + q;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) ig[q][g] = rr < rvt ? io.igates[(base + rr) * 3 * H + g * H + u] : 0.0f;
+        }
+        f32x4 a4[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) a4[jj] = *(const f32x4 *)(&cur[j][16 * jj + 4 * kq]);
+        // two partial sums per gate (k-halves of 64), added at the end: six independent MFMA chains in flight, and the rounding of a
+        // 128-term fp32 sum grows with the length of the chain
+        f32x4 acc2[2][3];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc2[hlf][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        acc2[hlf][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[4 * hlf + jj][c], bw[g][4 * hlf + jj][c], acc2[hlf][g], 0, 0, 0);
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = acc2[0][g] + acc2[1][g];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = 4 * kq + q;
+            if (rr < rvt) {
+                const float hn = acc[2][q] + bhn;
+                const float rg = sigmoidf_(ig[q][0] + acc[0][q] + bir);
+                const float zg = sigmoidf_(ig[q][1] + acc[1][q] + biz);
+                const float ng = tanhf(ig[q][2] + bin + rg * hn);
+                const float hp = cur[rr][u];
+                const float hnew = (1.0f - zg) * ng + zg * hp;
+                const size_t o = base + rr;
+                io.hs[o * H + u] = hnew;
+                if (io.gates) {
+                    io.gates[o * 4 * H + u] = rg; io.gates[o * 4 * H + H + u] = zg; io.gates[o * 4 * H + 2 * H + u] = ng;
+                    io.gates[o * 4 * H + 3 * H + u] = hn;
+                }
+                nxt[rr][u] = hnew;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 thread_local int g_last = 0;
 
 }  // namespace
@@ -281,6 +374,31 @@ int gru_seq_forward_packed(const float *d_igates, const float *d_h0, const float
                            int T, int64_t R, int hidden, const int32_t *step_rows, float *d_hs, float *d_gates, void *stream) {
     if (!step_rows) return CRNN_ERR_BAD_ARG;
     return seq_forward(d_igates, d_h0, d_w_hh, d_b_ih, d_b_hh, T, R, hidden, step_rows, d_hs, d_gates, stream);
+}
+
+int gru_seq_forward_packed_pair(const float *d_igates_a, const float *d_h0_a, const float *d_w_hh_a, const float *d_b_ih_a,
+                                const float *d_b_hh_a, float *d_hs_a, float *d_gates_a, const float *d_igates_b, const float *d_h0_b,
+                                const float *d_w_hh_b, const float *d_b_ih_b, const float *d_b_hh_b, float *d_hs_b, float *d_gates_b,
+                                int T, int64_t R, int hidden, const int32_t *step_rows, void *stream) {
+    if (!d_igates_a || !d_w_hh_a || !d_b_ih_a || !d_b_hh_a || !d_hs_a || T < 0 || R < 0 || !step_rows) return CRNN_ERR_BAD_ARG;
+    const bool two = d_igates_b != nullptr;
+    if (two && (!d_w_hh_b || !d_b_ih_b || !d_b_hh_b || !d_hs_b)) return CRNN_ERR_BAD_ARG;
+    if ((((size_t)d_w_hh_a | (size_t)d_w_hh_b) & 15) != 0) return CRNN_ERR_BAD_ARG;
+    if (hidden != H) return CRNN_ERR_UNSUPPORTED;
+    if (T == 0 || R == 0) return CRNN_OK;
+    SeqOff so;
+    const int rc = make_seq_off(step_rows, T, R, so);
+    if (rc != CRNN_OK) return rc;
+    const long per_net = (R + kMW - 1) / kMW;
+    if (per_net * 2 > 0x7fffffffL) return CRNN_ERR_BAD_ARG;
+    const GruNetIO a{d_igates_a, d_h0_a, d_w_hh_a, d_b_ih_a, d_b_hh_a, d_hs_a, d_gates_a};
+    const GruNetIO b{d_igates_b, d_h0_b, d_w_hh_b, d_b_ih_b, d_b_hh_b, d_hs_b, d_gates_b};
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_gru_seq_fwd_mfma, dim3((unsigned)(per_net * (two ? 2 : 1))), dim3(kBlock), 0, (hipStream_t)stream, a, two ? b : a,
+                       (int)per_net, T, (long)R, so);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last = (int)e; return CRNN_ERR_HIP; }
+    return CRNN_OK;
 }
 
 static int seq_backward(const float *d_grad_hs, const float *d_gates, const float *d_hs, const float *d_h0, const float *d_w_hh,

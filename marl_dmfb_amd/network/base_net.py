@@ -417,6 +417,46 @@ class _GRUSeqHipPacked(torch.autograd.Function):
         return d_ig, d_h0, d_w_hh, d_b[:3 * H], d_b[3 * H:], None
 
 
+class _GRUSeqPairPacked(torch.autograd.Function):
+    """The packed GRU recurrence of TWO networks over the same batch in one launch (include/crnn_ops.h:
+    gru_seq_forward_packed_pair): network a with gradients (the eval net of VDN.learn: gates saved, backward =
+    gru_seq_backward_packed), network b without (the target net).  Zero initial state.  Returns (hs_a, hs_b)."""
+
+    @staticmethod
+    def forward(ctx, ig_a, w_hh_a, b_ih_a, b_hh_a, ig_b, w_hh_b, b_ih_b, b_hh_b, step_rows, R):
+        import ctypes as C
+        lib = _GRUSeqHip._lib()
+        Vp, G = ig_a.shape
+        Hd, T, V = G // 3, len(step_rows), int(sum(step_rows))
+        save = any(ctx.needs_input_grad[:4])
+        ta = [t.detach().contiguous() for t in (ig_a, w_hh_a, b_ih_a, b_hh_a)]
+        tb = [t.detach().contiguous() for t in (ig_b, w_hh_b, b_ih_b, b_hh_b)]
+        hs_a = torch.empty((Vp, Hd), dtype=torch.float32, device=ig_a.device)
+        hs_b = torch.empty((Vp, Hd), dtype=torch.float32, device=ig_a.device)
+        hs_a[V:].zero_()
+        hs_b[V:].zero_()
+        gates = torch.empty((Vp, 4 * Hd), dtype=torch.float32, device=ig_a.device) if save else None
+        vp = C.c_void_p
+        rc = lib.gru_seq_forward_packed_pair(vp(ta[0].data_ptr()), None, vp(ta[1].data_ptr()), vp(ta[2].data_ptr()), vp(ta[3].data_ptr()),
+                                             vp(hs_a.data_ptr()), vp(gates.data_ptr()) if save else None,
+                                             vp(tb[0].data_ptr()), None, vp(tb[1].data_ptr()), vp(tb[2].data_ptr()), vp(tb[3].data_ptr()),
+                                             vp(hs_b.data_ptr()), None, T, R, Hd, _GRUSeqHipPacked._steps(step_rows),
+                                             vp(torch.cuda.current_stream(ig_a.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError('gru_seq_forward_packed_pair failed: %d (hip %d)' % (rc, lib.gru_last_hip_error()))
+        if save:
+            h0 = torch.zeros((R, Hd), dtype=torch.float32, device=ig_a.device)
+            ctx.save_for_backward(hs_a, gates, h0, ta[1])
+            ctx.step_rows = list(step_rows)
+        ctx.mark_non_differentiable(hs_b)
+        return hs_a, hs_b
+
+    @staticmethod
+    def backward(ctx, grad_a, _grad_b):
+        d_ig, _d_h0, d_w_hh, d_b_ih, d_b_hh, _ = _GRUSeqHipPacked.backward(ctx, grad_a)
+        return d_ig, d_w_hh, d_b_ih, d_b_hh, None, None, None, None, None, None
+
+
 def gru_sequence(igates, h0, w_hh, b_ih, b_hh, impl='hip'):
     """hs (T, R, H) of the GRU recurrence given the input-side pre-activations of all steps."""
     if impl == 'hip' and h0.shape[-1] == 128 and igates.dtype == torch.float32:
@@ -531,6 +571,26 @@ class CRNN(nn.Module):
         else:
             hs = _GRUSeqHipPacked.run_forward(*args, step_rows, False)[0]
         return _LinearSplitK.apply(hs, self.fc1.weight, self.fc1.bias)
+
+    @staticmethod
+    def recurrent_seq_packed_pair(net_a, x_a, net_b, x_b, step_rows, R):
+        """`recurrent_seq_packed` of two networks over the same packed batch (the eval net `net_a`, with gradients, and the target net
+        `net_b` under no_grad) with ONE launch for the two recurrences (include/crnn_ops.h: gru_seq_forward_packed_pair).
+        Returns (q_a, q_b), each (V_pad, A)."""
+        def w_ih(net, x, grad):
+            if x.shape[-1] == net.padded_cols() != net.rnn.weight_ih.shape[1]:
+                return net.weight_ih_padded() if grad else net.refresh_padded()
+            return net.rnn.weight_ih
+        ig_a = _LinearSplitK.apply(x_a, w_ih(net_a, x_a, True), None)
+        with torch.no_grad():
+            ig_b = torch.matmul(x_b, w_ih(net_b, x_b, False).t())
+        hs_a, hs_b = _GRUSeqPairPacked.apply(ig_a, net_a.rnn.weight_hh, net_a.rnn.bias_ih, net_a.rnn.bias_hh,
+                                             ig_b, net_b.rnn.weight_hh.detach(), net_b.rnn.bias_ih.detach(), net_b.rnn.bias_hh.detach(),
+                                             step_rows, R)
+        q_a = _LinearSplitK.apply(hs_a, net_a.fc1.weight, net_a.fc1.bias)
+        with torch.no_grad():
+            q_b = torch.addmm(net_b.fc1.bias, hs_b, net_b.fc1.weight.t())
+        return q_a, q_b
 
     def forward(self, inputs, hidden_state):
         """Reference signature: inputs (R, obs+n_actions) float32, hidden (R, H) -> (q, h)."""

@@ -405,9 +405,13 @@ class VDN:
         with torch.no_grad():
             x_t = self._features(self.target_rnn, obs_t, oh_t)
         step_rows = [int(c) * n for c in counts]
-        q_e = self.eval_rnn.recurrent_seq_packed(x_e, step_rows, B * n)
-        with torch.no_grad():
-            q_t = self.target_rnn.recurrent_seq_packed(x_t, step_rows, B * n)
+        if os.environ.get('MARL_DMFB_GRU_PAIR', '1') != '0' and hasattr(self.eval_rnn, 'recurrent_seq_packed_pair'):
+            # the two networks' recurrences in one launch on the matrix cores (include/crnn_ops.h: gru_seq_forward_packed_pair)
+            q_e, q_t = self.eval_rnn.recurrent_seq_packed_pair(self.eval_rnn, x_e, self.target_rnn, x_t, step_rows, B * n)
+        else:
+            q_e = self.eval_rnn.recurrent_seq_packed(x_e, step_rows, B * n)
+            with torch.no_grad():
+                q_t = self.target_rnn.recurrent_seq_packed(x_t, step_rows, B * n)
         if self._td_bad is None:
             self._td_bad = torch.zeros(1, dtype=torch.int32, device=dev)
         num, mask_sum = _TDLossPacked.apply(q_e, q_t, units, U, buffers['u'], buffers['r'], buffers['avail_u_next'],

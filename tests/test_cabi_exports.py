@@ -88,7 +88,7 @@ def test_crnn_ops_library_exports():
                      'crnn_front9_forward', 'crnn_front9_forward_live',
                      'crnn_front_padded_cols', 'crnn_last_hip_error', 'crnn_mlp_backward', 'crnn_mlp_backward_parts']
     gru = sorted(set(re.findall(r'\b(gru_[a-z_0-9]+)\s*\(', txt)))
-    assert gru == ['gru_last_hip_error', 'gru_seq_backward', 'gru_seq_backward_packed', 'gru_seq_forward', 'gru_seq_forward_packed',
+    assert gru == ['gru_last_hip_error', 'gru_seq_backward', 'gru_seq_backward_packed', 'gru_seq_forward', 'gru_seq_forward_packed', 'gru_seq_forward_packed_pair',
                    'gru_seq_row_blocks']
     assert lib.gru_seq_forward_packed(None, None, None, None, None, 4, 8, 128, None, None, None, None) == -1
     for n in names + gru:

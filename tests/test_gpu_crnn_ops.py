@@ -386,3 +386,84 @@ def test_mlp_branch_backward_matches_float64(rows, A, dir_off, col0, pad):
                                  vp(grad.data_ptr()), grad.stride(0), col0, vp(part.data_ptr()), vp(g_w.data_ptr()), vp(g_b.data_ptr()), None) != 0
     assert lib.crnn_mlp_backward(vp(obs.data_ptr()), obs.stride(0), dir_off, oh_ptr, A, rows, vp(x.data_ptr()), col0 + 9,
                                  vp(grad.data_ptr()), grad.stride(0), col0, vp(part.data_ptr()), vp(g_w.data_ptr()), vp(g_b.data_ptr()), None) != 0
+
+
+@pytest.mark.parametrize('R,lens', [(1, [3]), (37, None), (2048, None), (520, 'full')])
+def test_gru_pair_forward_matches_float64_and_the_packed_kernel(R, lens):
+    """gru_seq_forward_packed_pair (two networks, recurrence on the matrix cores, 16 rows per workgroup) on ragged packed sequences
+    against nn.GRUCell unrolled in float64 (network/base_net.py:56,69; policy/vdn.py:174-191; 2e-5 on h as for the VALU kernel),
+    against gru_seq_forward_packed on the same inputs (hs and the saved gates, 1e-5), through the autograd node (gradients of network
+    a = those of _GRUSeqHipPacked on the same forward), and with network b absent."""
+    import ctypes as C
+    from marl_dmfb_amd import _lib
+    from marl_dmfb_amd.network.base_net import _GRUSeqHipPacked, _GRUSeqPairPacked
+    lib = _lib.crnn_ops()
+    H, T = 128, 12
+    g = torch.Generator().manual_seed(R)
+    if lens is None:
+        ln = torch.sort(torch.randint(1, T + 1, (R,), generator=g), descending=True).values.tolist()
+    elif lens == 'full':
+        ln = [T] * R
+    else:
+        ln = lens
+    Tm = max(ln)
+    step_rows = [sum(1 for v in ln if v > t) for t in range(Tm)]
+    V = sum(step_rows)
+    Vp = -(-V // 64) * 64
+    torch.manual_seed(R + 1)
+    cells = [torch.nn.GRUCell(H, H).cuda() for _ in range(2)]
+    igs = [torch.randn(Vp, 3 * H, device='cuda') for _ in range(2)]
+    for ig in igs:
+        ig[V:].zero_()
+    h0 = torch.zeros(R, H, device='cuda')
+    ig_a = igs[0].clone().requires_grad_(True)
+    hs_a, hs_b = _GRUSeqPairPacked.apply(ig_a, cells[0].weight_hh, cells[0].bias_ih, cells[0].bias_hh,
+                                         igs[1], cells[1].weight_hh.detach(), cells[1].bias_ih.detach(), cells[1].bias_hh.detach(), step_rows, R)
+    assert not hs_b.requires_grad and hs_a.requires_grad
+    # float64 reference, per network: unroll the cell on the rows still running
+    for k, hs in enumerate((hs_a, hs_b)):
+        c = cells[k]
+        w, bi, bh = c.weight_hh.detach().double().cpu(), c.bias_ih.detach().double().cpu(), c.bias_hh.detach().double().cpu()
+        ig64 = igs[k].double().cpu()
+        h = torch.zeros(R, H, dtype=torch.float64)
+        off = 0
+        for t in range(Tm):
+            rt = step_rows[t]
+            gi = ig64[off:off + rt] + bi
+            gh = h[:rt] @ w.t() + bh
+            r_ = torch.sigmoid(gi[:, :H] + gh[:, :H])
+            z_ = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+            n_ = torch.tanh(gi[:, 2 * H:] + r_ * gh[:, 2 * H:])
+            hn = (1 - z_) * n_ + z_ * h[:rt]
+            np.testing.assert_allclose(hs.detach()[off:off + rt].cpu().numpy(), hn.numpy(), rtol=0, atol=2e-5)
+            h = h.clone()
+            h[:rt] = hn
+            off += rt
+        assert float(hs.detach()[V:].abs().max()) == 0.0 if Vp > V else True
+    # the VALU kernel on the same inputs: outputs and saved gates
+    ig_v = igs[0].clone().requires_grad_(True)
+    hs_v = _GRUSeqHipPacked.apply(ig_v, h0, cells[0].weight_hh, cells[0].bias_ih, cells[0].bias_hh, step_rows)
+    np.testing.assert_allclose(hs_a.detach().cpu().numpy(), hs_v.detach().cpu().numpy(), rtol=0, atol=1e-5)
+    gout = torch.randn(Vp, H, device='cuda')
+    gout[V:].zero_()
+    params = (cells[0].weight_hh, cells[0].bias_ih, cells[0].bias_hh)
+    for p in params:
+        p.grad = None
+    (hs_a * gout).sum().backward()
+    got = [ig_a.grad.clone()] + [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    (hs_v * gout).sum().backward()
+    want = [ig_v.grad.clone()] + [p.grad.clone() for p in params]
+    for a_, b_ in zip(got, want):
+        assert torch.linalg.norm(a_.double() - b_.double()) <= 1e-4 * torch.linalg.norm(b_.double()) + 1e-9
+    # one network only (d_igates_b NULL)
+    vp = C.c_void_p
+    hs1 = torch.full((Vp, H), 9.0, device='cuda')
+    st = (C.c_int32 * len(step_rows))(*step_rows)
+    rc = lib.gru_seq_forward_packed_pair(vp(igs[1].data_ptr()), None, vp(cells[1].weight_hh.data_ptr()), vp(cells[1].bias_ih.data_ptr()),
+                                         vp(cells[1].bias_hh.data_ptr()), vp(hs1.data_ptr()), None, None, None, None, None, None, None, None,
+                                         Tm, R, H, st, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(hs1[:V], hs_b.detach()[:V])
