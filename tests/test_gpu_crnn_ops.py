@@ -467,3 +467,48 @@ def test_gru_pair_forward_matches_float64_and_the_packed_kernel(R, lens):
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(hs1[:V], hs_b.detach()[:V])
+
+
+@pytest.mark.parametrize('R', [1, 37, 530])
+def test_gru_packed_backward_matches_float64_autograd(R):
+    """gru_seq_backward_packed behind the packed autograd node, on ragged sequences, against float64 autograd through an unrolled
+    nn.GRUCell (policy/vdn.py:174-191): relative L2 2e-4 on every gradient, as for the time-major kernels."""
+    from marl_dmfb_amd.network.base_net import _GRUSeqHipPacked
+    H, T = 128, 9
+    g = torch.Generator().manual_seed(R)
+    ln = torch.sort(torch.randint(1, T + 1, (R,), generator=g), descending=True).values.tolist()
+    Tm = max(ln)
+    step_rows = [sum(1 for v in ln if v > t) for t in range(Tm)]
+    V = sum(step_rows)
+    Vp = -(-V // 64) * 64
+    torch.manual_seed(R + 5)
+    cell = torch.nn.GRUCell(H, H).cuda()
+    ig = torch.randn(Vp, 3 * H, device='cuda')
+    ig[V:].zero_()
+    ig.requires_grad_(True)
+    h0 = torch.zeros(R, H, device='cuda')
+    gout = torch.randn(Vp, H, device='cuda')
+    gout[V:].zero_()
+    hs = _GRUSeqHipPacked.apply(ig, h0, cell.weight_hh, cell.bias_ih, cell.bias_hh, step_rows)
+    (hs * gout).sum().backward()
+    got = [t.grad.detach().double().cpu() for t in (ig, cell.weight_hh, cell.bias_ih, cell.bias_hh)]
+    w = cell.weight_hh.detach().double().cpu().requires_grad_(True)
+    bi = cell.bias_ih.detach().double().cpu().requires_grad_(True)
+    bh = cell.bias_hh.detach().double().cpu().requires_grad_(True)
+    ig64 = ig.detach().double().cpu().requires_grad_(True)
+    h = torch.zeros(R, H, dtype=torch.float64)
+    loss, off = 0.0, 0
+    for t in range(Tm):
+        rt = step_rows[t]
+        gi = ig64[off:off + rt] + bi
+        gh = h[:rt] @ w.t() + bh
+        r_ = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z_ = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n_ = torch.tanh(gi[:, 2 * H:] + r_ * gh[:, 2 * H:])
+        hn = (1 - z_) * n_ + z_ * h[:rt]
+        loss = loss + (hn * gout[off:off + rt].double().cpu()).sum()
+        h = torch.cat([hn, h[rt:]], 0)
+        off += rt
+    loss.backward()
+    for a_, b_ in zip(got, (ig64.grad, w.grad, bi.grad, bh.grad)):
+        assert torch.linalg.norm(a_ - b_) <= 2e-4 * torch.linalg.norm(b_) + 1e-9
