@@ -28,6 +28,9 @@ def main():
     ap.add_argument('--width', type=int, default=20)
     ap.add_argument('--drop_num', type=int, default=10)
     ap.add_argument('--n_envs', type=int, default=4096)
+    ap.add_argument('--block_num', type=int, default=0, help='obstacle blocks per chip (SURVEY 8 f4: GenRandomBlocks, dmfb.py:228-251)')
+    ap.add_argument('--no_stall', action='store_true', help='stall=False (dmfb.py:331,345-346)')
+    ap.add_argument('--no_sweep', action='store_true', help='training and evaluations only')
     ap.add_argument('--rounds', type=int, default=3125, help='rounds of one episode per chip (3125 x 4 learns = the reference\'s 12 500 learns)')
     ap.add_argument('--seconds', type=float, default=900.0, help='wall-clock cap of the training loop')
     ap.add_argument('--train_time', type=int, default=4)
@@ -52,7 +55,7 @@ def main():
 
     W, n, E = a.width, a.drop_num, a.n_envs
     torch.manual_seed(a.seed)
-    env = VecDMFB(W, W, n, fov=9, n_envs=E, seed=a.seed, device='cuda:0')
+    env = VecDMFB(W, W, n, a.block_num, fov=9, stall=not a.no_stall, n_envs=E, seed=a.seed, device='cuda:0')
     info = env.get_env_info()
     T = info['episode_limit']
     args = make_args(drop_num=n, width=W, length=W, fov=9, device='cuda:0', n_envs=E, batch_size=a.batch_size,
@@ -62,7 +65,7 @@ def main():
         args.model_dir = a.load
         args.load_model_name = '0_'
     tr = Trainer(env, args)
-    emit(what='config', width=W, drop_num=n, n_envs=E, od=args.hyper_hidden_dim, train_time=a.train_time, batch_size=a.batch_size,
+    emit(what='config', width=W, drop_num=n, block_num=a.block_num, stall=not a.no_stall, n_envs=E, od=args.hyper_hidden_dim, train_time=a.train_time, batch_size=a.batch_size,
          buffer=args.buffer_size, anneal_steps=args.anneal_steps, lr=args.lr, target_update_cycle=args.target_update_cycle,
          ref_yaml=TRAIN_PARAS[('dmfb', n)] if ('dmfb', n) in TRAIN_PARAS else None)
     env_steps, t0 = 0, time.time()
@@ -79,6 +82,8 @@ def main():
             if time.time() - t0 > a.seconds:
                 break
         tr.agents.policy.save_model()
+    if a.no_sweep:
+        return
     # ---- the sweep of evaDegre.py:29-56
     t1 = time.time()
     env2 = VecDMFB(W, W, n, fov=9, stall=True, b_degrade=True, per_degrade=1.0, n_envs=a.chips, seed=1, device='cuda:0')
