@@ -155,12 +155,37 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
     const int ra = 2 * q;
     float gh[2] = {0.0f, 0.0f};  // dL/dh_t arriving from the future for my two (row, u) entries
     float bs_r = 0.0f, bs_z = 0.0f, bs_n = 0.0f, bs_hn = 0.0f;  // column sums of the gate gradients (bias gradients)
-    for (int t = T - 1; t >= 0; --t) {
-        const long rt = so.packed ? (long)(so.off[t + 1] - so.off[t]) : R;   // rows running at step t (see k_gru_seq_fwd)
-        if (row0 >= rt) continue;  // uniform: none of this workgroup's sequences reaches step t
+    // steps this workgroup takes part in: 0 .. t_last (packed: the rows are sorted by length, the running rows only shrink with t)
+    int t_last = -1;
+    for (int t = 0; t < T; ++t)
+        if (row0 < (so.packed ? (long)(so.off[t + 1] - so.off[t]) : R)) t_last = t;
+    // The six inputs of a (row, unit) entry do not depend on the recurrence: those of step t - 1 are requested while step t's dot
+    // products run, so that no step starts with a global-memory round trip.
+    struct In { float g, rg, zg, ng, hn, hp; };
+    In cur[2], nx[2];
+    auto fetch = [&](int t, In (&in)[2]) __attribute__((always_inline)) {
+        const long rt = so.packed ? (long)(so.off[t + 1] - so.off[t]) : R;
         const int rvt = (int)min((long)rv, rt - row0);
         const size_t base = so.packed ? (size_t)so.off[t] : (size_t)t * R;
         const size_t base_prev = so.packed ? (size_t)so.off[t > 0 ? t - 1 : 0] : (size_t)(t > 0 ? t - 1 : 0) * R;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int rr = ra + s;
+            const bool on = rr < rvt;
+            const size_t o = base + row0 + (on ? rr : 0);
+            in[s].g = on ? grad_hs[o * H + u] : 0.0f;
+            in[s].rg = on ? gates[o * 4 * H + u] : 0.0f;
+            in[s].zg = on ? gates[o * 4 * H + H + u] : 0.0f;
+            in[s].ng = on ? gates[o * 4 * H + 2 * H + u] : 0.0f;
+            in[s].hn = on ? gates[o * 4 * H + 3 * H + u] : 0.0f;
+            in[s].hp = !on ? 0.0f : t > 0 ? hs[(base_prev + row0 + rr) * H + u] : h0[(row0 + rr) * H + u];
+        }
+    };
+    if (t_last >= 0) fetch(t_last, cur);
+    for (int t = t_last; t >= 0; --t) {
+        const long rt = so.packed ? (long)(so.off[t + 1] - so.off[t]) : R;   // rows running at step t (see k_gru_seq_fwd)
+        const int rvt = (int)min((long)rv, rt - row0);
+        const size_t base = so.packed ? (size_t)so.off[t] : (size_t)t * R;
         float direct[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -169,10 +194,9 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
             direct[s] = 0.0f;
             if (rr < rvt) {
                 const size_t o = base + row0 + rr;
-                const float g = grad_hs[o * H + u] + gh[s];
-                const float rg = gates[o * 4 * H + u], zg = gates[o * 4 * H + H + u], ng = gates[o * 4 * H + 2 * H + u],
-                            hn = gates[o * 4 * H + 3 * H + u];
-                const float hp = t > 0 ? hs[(base_prev + row0 + rr) * H + u] : h0[(row0 + rr) * H + u];
+                const float g = cur[s].g + gh[s];
+                const float rg = cur[s].rg, zg = cur[s].zg, ng = cur[s].ng, hn = cur[s].hn;
+                const float hp = cur[s].hp;
                 if (h_prev_out) h_prev_out[o * H + u] = hp;  // h_{t-1} in the layout of d_hgates: dW_hh = d_hgates^T h_prev is ONE GEMM
                 const float dn = g * (1.0f - zg), dz = g * (hp - ng);
                 direct[s] = g * zg;
@@ -186,6 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
             }
             s_dhg[rr >> 1][0][u][rr & 1] = dpr; s_dhg[rr >> 1][1][u][rr & 1] = dpz; s_dhg[rr >> 1][2][u][rr & 1] = dhn;
         }
+        if (t > 0) fetch(t - 1, nx);
         __syncthreads();
         // partial W_hh^T d_hgates over my k-quarter of the gate rows, output column u, all RW rows, two rows per instruction
 #pragma unroll
@@ -211,6 +236,7 @@ __global__ __launch_bounds__(kBlock) void k_gru_seq_bwd(const float *__restrict_
         for (int s = 0; s < 2; ++s) {
             const int rr = ra + s;
             gh[s] = direct[s] + s_part[0][rr][u] + s_part[1][rr][u] + s_part[2][rr][u] + s_part[3][rr][u];
+            cur[s] = nx[s];
         }
         // the next iteration writes s_dhg only after its first barrier's predecessor: all reads of s_dhg above are
         // complete (second barrier), and s_part is rewritten only after the next first barrier
